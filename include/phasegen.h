@@ -1,0 +1,136 @@
+/* phasegen.h -- C ABI of libphasegen.so: the MI355X (gfx950) hot path of UNet-PhaseGen.
+ *
+ * The reference (LemonATsu/UNet-PhaseGen) is pure Python and has no FFI of its own; what it binds on
+ * this path is torch.nn.Conv1d / ConvTranspose1d / BatchNorm / (Leaky)ReLU / cat (model.py:77-113),
+ * MSELoss + Adam (train.py:26-28,45-62), np.abs/np.angle (data.py:39-47) and librosa.stft / istft
+ * (preproc_mdb.py:93, utils.py:40).  Each entry point below replaces one of those and cites it.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, scalars; no torch types.  All tensors fp32.
+ *   - activations are (B, channels, frames), frames fastest; a tensor is given as {ptr, batch_stride}
+ *     (elements) so a channel slice of a wider buffer (the U-Net's concat halves) is passed without copy.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing and keeps
+ *     no mutable global state besides a thread-local last-error string.
+ *   - every call is asynchronous on the hipStream_t passed as `void* stream`; no internal syncs.
+ *   - return 0 on success, <0 = PG_ERR_* (bad argument), >0 = hipError_t from the launch.
+ */
+#ifndef PHASEGEN_H
+#define PHASEGEN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_VERSION 100 /* 0.1.0 */
+
+enum { PG_OK = 0, PG_ERR_NULL = -1, PG_ERR_SHAPE = -2, PG_ERR_ALIGN = -3, PG_ERR_UNSUPPORTED = -4,
+       PG_ERR_WORKSPACE = -5 };
+
+/* activation fused on operand load / derivative mask fused in a dgrad epilogue */
+enum { PG_ACT_NONE = 0, PG_ACT_LEAKY02 = 1 /* nn.LeakyReLU(0.2), model.py:80 */, PG_ACT_RELU = 2 /* model.py:82 */ };
+
+/* One descriptor serves the six convolution entry points.  Geometry is always that of the FORWARD op:
+ *   Conv1d          x (B,Cin,Lin) * w (Cout,Cin,k)  -> y (B,Cout,Lout),  Lout = (Lin + 2 pad - k)/stride + 1
+ *   ConvTranspose1d x (B,Cin,Lin) * w (Cin,Cout,k)  -> y (B,Cout,Lout),  Lout = (Lin - 1) stride - 2 pad + k
+ * bias is never used (model.py:65-69: use_bias == False under BatchNorm). */
+typedef struct pg_conv_args {
+    int32_t B, Cin, Cout, Lin, Lout, k, stride, pad;
+    const float* x;  int64_t x_bs;   /* forward input; read by *_fwd and *_wgrad                           */
+    int32_t x_act;                   /* PG_ACT_* applied to x as it is read (the in-place (Leaky)ReLU that  */
+    int32_t _pad0;                   /*   precedes the conv in model.py:91,96,103 is never materialised)    */
+    const float* w;                  /* weights (layout above); read by *_fwd and *_dgrad                  */
+    float* y;        int64_t y_bs;   /* forward output; written by *_fwd                                   */
+    const float* dy; int64_t dy_bs;  /* grad wrt y; read by *_dgrad and *_wgrad                            */
+    float* dx;       int64_t dx_bs;  /* grad wrt the tensor x was read from; written by *_dgrad            */
+    const float* dx_add; int64_t dx_add_bs; /* optional (NULL): added to the dgrad result before masking (skip grad) */
+    const float* dx_ref; int64_t dx_ref_bs; /* optional (NULL): dx *= act'(dx_ref) with act = dx_mask              */
+    int32_t dx_mask; int32_t _pad1;
+    float* dw;                       /* grad wrt w, same layout as w; OVERWRITTEN by *_wgrad (beta = 0:     */
+                                     /*   optim.zero_grad(), train.py:41, is folded into the write)         */
+} pg_conv_args;
+
+/* nn.Conv1d forward / backward (model.py:77-78; autograd of train.py:61) */
+int pg_conv1d_fwd(const pg_conv_args* a, void* stream);
+int pg_conv1d_dgrad(const pg_conv_args* a, void* stream);
+int pg_conv1d_wgrad(const pg_conv_args* a, void* stream);
+/* nn.ConvTranspose1d forward / backward (model.py:88-89,94-95,101-102) */
+int pg_convt1d_fwd(const pg_conv_args* a, void* stream);
+int pg_convt1d_dgrad(const pg_conv_args* a, void* stream);
+int pg_convt1d_wgrad(const pg_conv_args* a, void* stream);
+
+/* Train-mode batch norm over (B, L) per channel (model.py:81,83 applied to 3-D tensors; eps 1e-5, momentum
+ * 0.1; biased variance normalises, unbiased variance goes to running_var). */
+typedef struct pg_bn_args {
+    int32_t B, C, L; float eps, momentum;
+    const float* x;  int64_t x_bs;       /* raw conv output                                  */
+    float* y;        int64_t y_bs;       /* fwd: normalised + affine output                  */
+    const float* gamma; const float* beta;
+    float* save_mean; float* save_invstd;     /* (C) written by fwd, read by bwd             */
+    float* running_mean; float* running_var;  /* (C) updated in place by fwd; may be NULL    */
+    const float* dy; int64_t dy_bs;      /* bwd: grad wrt y                                  */
+    float* dx;       int64_t dx_bs;      /* bwd: grad wrt x                                  */
+    float* dgamma; float* dbeta;         /* bwd: (C), overwritten                            */
+} pg_bn_args;
+int pg_bn_fwd(const pg_bn_args* a, void* stream);
+int pg_bn_bwd(const pg_bn_args* a, void* stream);
+
+/* train.py:45-60: loss = MSE(cos p, cos th) + MSE(sin p, sin th) + mag_weight * MSE(m, logmag), fused with its
+ * gradient wrt pred.  pred (B,2C,L) = [phase ; magnitude]; batch (B,2,C,L) = [logmag ; angle].
+ * losses[0..2] = {loss, ang, mag}.  Deterministic two-stage reduction through `workspace`. */
+typedef struct pg_loss_args {
+    int32_t B, C, L; float mag_weight;
+    const float* pred; const float* batch;
+    float* dpred;      /* may be NULL (evaluation only) */
+    float* losses;     /* 3 floats, device */
+    void* workspace; int64_t workspace_bytes;
+} pg_loss_args;
+int64_t pg_workspace_bytes_loss(const pg_loss_args* a);
+int pg_loss_fwd_bwd(const pg_loss_args* a, void* stream);
+
+/* torch.optim.Adam.step with defaults (train.py:27,62) over one flat parameter arena: p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps).
+ * grad_scale multiplies g first (1/world for data-parallel averaging); step is 1-based. */
+typedef struct pg_adam_args {
+    int64_t n; float* p; const float* g; float* m; float* v;
+    double lr, beta1, beta2, eps, grad_scale;   /* Python floats, rounded to fp32 exactly where torch rounds them */
+    int32_t step; int32_t _pad0;
+} pg_adam_args;
+int pg_adam_step(const pg_adam_args* a, void* stream);
+
+/* librosa.stft(y, n_fft, hop) + DC drop + [re; im] stacking (preproc_mdb.py:84-97), optionally fused with
+ * data.py:39-47 (polar = 1 -> out = [log1p|z| ; angle z]).  y (n_signals, n_samples) -> out (n_signals, 2, n_fft/2, n_frames),
+ * n_frames = 1 + n_samples / hop, reflect padding n_fft/2, periodic Hann.  n_fft: power of two in [32, 4096]. */
+typedef struct pg_stft_args {
+    int32_t n_signals, n_samples, n_fft, hop, n_frames, polar;
+    const float* y; float* out;
+} pg_stft_args;
+int pg_stft(const pg_stft_args* a, void* stream);
+/* The integer framing map alone (bit-exact contract): idx[t, k] = sample index of tap k of frame t. */
+int pg_stft_frame_index(int32_t n_samples, int32_t n_fft, int32_t hop, int32_t n_frames, int32_t* idx, void* stream);
+
+/* data.py:39-47 on its own: in (N,2,...) [re; im] -> out (N,2,...) [log1p|z| ; angle]; inner = bins*frames. */
+typedef struct pg_polar_args { int64_t n_items; int64_t inner; const float* in; float* out; } pg_polar_args;
+int pg_polar(const pg_polar_args* a, void* stream);
+
+/* demo.py:39 + utils.py:34-42: z = (exp(logmag) - 1) e^{j phase} (mode 0) or re + j im (mode 1); zero DC row prepended;
+ * librosa.istft (irfft x Hann, overlap-add, / window-sum-square, trim n_fft/2); optional peak normalisation.
+ * a, b: (n_signals, bins, n_frames) with the given batch strides; audio (n_signals, hop * (n_frames - 1)). */
+typedef struct pg_istft_args {
+    int32_t n_signals, bins, n_frames, hop, mode, normalize;
+    const float* a; int64_t a_bs; const float* b; int64_t b_bs;
+    float* audio;
+    void* workspace; int64_t workspace_bytes;
+} pg_istft_args;
+int64_t pg_workspace_bytes_istft(const pg_istft_args* a);
+int pg_istft(const pg_istft_args* a, void* stream);
+
+/* small helpers the training step needs on device */
+int pg_fill(float* p, int64_t n, float value, void* stream);
+
+int pg_version(void);
+const char* pg_last_error_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHASEGEN_H */

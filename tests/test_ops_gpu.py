@@ -1,0 +1,171 @@
+"""GPU parity of every conv / BN / loss / Adam kernel against stock fp32 torch CPU ops (the oracle's building
+blocks: F.conv1d, F.conv_transpose1d and their autograd), through the C ABI.  Tolerance: 1e-4 relative to the
+tensor's max-abs (BASELINE.json: "within 1e-4 rel fp32"); observed errors are ~1e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_ref  # noqa: F401  (disables oneDNN: see the bug note in oracle/unet_ref.py)
+from phasegen import detgen
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def act_cpu(x, act):
+    return F.leaky_relu(x, 0.2) if act == 1 else (F.relu(x) if act == 2 else x)
+
+
+def rnd(seed, *shape):
+    return torch.from_numpy(detgen.uniform(seed, shape, -1.0, 1.0))
+
+
+# (transposed, Cin, Cout, k, s, p, Lin, B): every layer geometry of the U-Net at small and mid channel counts,
+# plus ragged sizes that leave partial tiles in M, N and K and a geometry that uses the runtime-(k,s) fallback.
+GEOMS = [
+    (False, 8, 16, 32, 2, 16, 24, 1), (False, 16, 16, 8, 1, 2, 13, 3), (False, 16, 16, 8, 2, 1, 10, 3),
+    (False, 16, 32, 4, 2, 1, 3, 2), (True, 32, 16, 5, 2, 1, 1, 2), (True, 32, 16, 8, 2, 1, 3, 3),
+    (True, 32, 16, 8, 1, 2, 10, 3), (True, 32, 16, 32, 2, 16, 13, 1),
+    (False, 64, 160, 32, 2, 16, 128, 2), (False, 160, 136, 8, 1, 2, 65, 3), (False, 136, 130, 8, 2, 1, 62, 2),
+    (False, 130, 260, 4, 2, 1, 29, 3), (True, 260, 130, 5, 2, 1, 14, 3), (True, 264, 132, 8, 2, 1, 29, 2),
+    (True, 264, 132, 8, 1, 2, 62, 2), (True, 200, 140, 32, 2, 16, 65, 2),
+    (False, 24, 40, 7, 3, 2, 50, 2), (True, 24, 40, 7, 3, 2, 17, 2),
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv_fwd_dgrad_wgrad(geom, act):
+    from phasegen import ops
+    tr, Cin, Cout, k, s, p, Lin, B = geom
+    x = rnd(1, B, Cin, Lin)
+    w = rnd(2, *((Cin, Cout, k) if tr else (Cout, Cin, k))) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xa = act_cpu(xr, act)
+    xa.retain_grad()
+    yr = F.conv_transpose1d(xa, wr, stride=s, padding=p) if tr else F.conv1d(xa, wr, stride=s, padding=p)
+    dy = rnd(3, *yr.shape)
+    yr.backward(dy)
+
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    y = torch.full(yr.shape, float("nan"), device="cuda")
+    ops.conv_fwd(xd, wd, y, s, p, x_act=act, transposed=tr)
+    assert relerr(y, yr) < TOL
+
+    # dgrad wrt the (activated) operand the conv read: autograd's grad of xa
+    dx = torch.full(x.shape, float("nan"), device="cuda")
+    ops.conv_dgrad(dyd, wd, dx, s, p, transposed=tr)
+    assert relerr(dx, xa.grad) < TOL
+    # fused epilogue: (+ add) * act'(ref)  == grad wrt the pre-activation tensor plus a skip gradient
+    if act:
+        add = rnd(4, *x.shape)
+        dx2 = torch.full(x.shape, float("nan"), device="cuda")
+        ops.conv_dgrad(dyd, wd, dx2, s, p, transposed=tr, add=add.cuda(), ref=xd, mask=act)
+        slope = 0.2 if act == 1 else 0.0
+        want = (xa.grad + add) * torch.where(x > 0, torch.ones_like(x), torch.full_like(x, slope))
+        assert relerr(dx2, want) < TOL
+
+    dw = torch.full(w.shape, float("nan"), device="cuda")
+    ops.conv_wgrad(xd, dyd, dw, s, p, x_act=act, transposed=tr)
+    assert relerr(dw, wr.grad) < TOL
+
+
+def test_conv_on_concat_slices():
+    """Operands given as channel slices of a wider buffer (batch stride != C*L), as the U-Net concat does."""
+    from phasegen import ops
+    B, C, L = 3, 24, 29
+    cat = rnd(5, B, 2 * C, L)
+    w = rnd(6, 2 * C, 16, 8) * 0.1                       # ConvTranspose1d(2C -> 16, k8, s2, p1)
+    yr = F.conv_transpose1d(F.relu(cat), w, stride=2, padding=1)
+    catd = torch.empty(B, 2 * C, L, device="cuda")
+    catd[:, :C] = cat[:, :C].cuda()
+    catd[:, C:] = cat[:, C:].cuda()
+    y = torch.empty(yr.shape, device="cuda")
+    ops.conv_fwd(catd, w.cuda(), y, 2, 1, x_act=2, transposed=True)
+    assert relerr(y, yr) < TOL
+    w2 = rnd(7, 16, C, 8) * 0.1                          # Conv1d(C -> 16) reading only the first half
+    y2r = F.conv1d(F.leaky_relu(cat[:, :C], 0.2), w2, stride=1, padding=2)
+    y2 = torch.empty(y2r.shape, device="cuda")
+    ops.conv_fwd(catd[:, :C], w2.cuda(), y2, 1, 2, x_act=1)
+    assert relerr(y2, y2r) < TOL
+    out = torch.zeros(B, 32, y2r.shape[2], device="cuda")  # ... and writing into the second half of a wider buffer
+    ops.conv_fwd(catd[:, :C], w2.cuda(), out[:, 16:], 1, 2, x_act=1)
+    assert relerr(out[:, 16:], y2r) < TOL and float(out[:, :16].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 13), (3, 48, 62), (64, 40, 129), (2, 8, 300)])
+def test_bn_fwd_bwd(shape):
+    from phasegen import ops
+    B, C, L = shape
+    x = rnd(8, B, C, L) * 2 + 0.3
+    g = torch.from_numpy(detgen.uniform(9, (C,), 0.5, 1.5))
+    b = torch.from_numpy(detgen.uniform(10, (C,), -0.5, 0.5))
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    yr = F.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
+    dy = rnd(11, B, C, L)
+    yr.backward(dy)
+    xd = x.cuda()
+    y = torch.empty_like(xd)
+    sm, si = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rmd, rvd = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    ops.bn_fwd(xd, y, g.cuda(), b.cuda(), sm, si, rmd, rvd)
+    assert relerr(y, yr) < TOL
+    assert relerr(rmd, rm) < TOL and relerr(rvd, rv) < TOL
+    dx = torch.empty_like(xd)
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_bwd(xd, dy.cuda(), dx, g.cuda(), sm, si, dg, db)
+    assert relerr(dx, xr.grad) < TOL
+    assert relerr(dg, gr.grad) < TOL and relerr(db, br.grad) < TOL
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 24), (3, 16, 64), (5, 33, 77)])
+def test_loss_fwd_bwd(shape):
+    from phasegen import ops
+    B, C, L = shape
+    pred = (rnd(12, B, 2 * C, L) * 4).requires_grad_(True)
+    batch = torch.from_numpy(detgen.make_batch(B, C, L, seed=3))
+    loss, ang, mag = unet_ref.phase_loss(pred, batch)
+    loss.backward()
+    dpred = torch.empty(B, 2 * C, L, device="cuda")
+    out = ops.loss_fwd_bwd(pred.detach().cuda(), batch.cuda(), dpred)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.allclose(got, [loss.item(), ang.item(), mag.item()], rtol=1e-5)
+    assert relerr(dpred, pred.grad) < TOL
+
+
+def test_adam_matches_torch_optim():
+    from phasegen import ops
+    n = 100003
+    p0 = torch.from_numpy(detgen.uniform(13, (n,), -0.1, 0.1))
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p, m, v = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = torch.from_numpy(detgen.uniform(20 + step, (n,), -1e-2, 1e-2))
+        g[::7] = 0.0
+        pr.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g.cuda(), m, v, step)
+    assert relerr(p, pr) < 1e-6
+    st = opt.state[pr]
+    assert relerr(m, st["exp_avg"]) < 1e-6 and relerr(v, st["exp_avg_sq"]) < 1e-6
+
+
+def test_bad_arguments_raise():
+    from phasegen import ops
+    x = torch.zeros(2, 8, 24, device="cuda")
+    w = torch.zeros(16, 8, 32, device="cuda")
+    with pytest.raises(ValueError):
+        ops.conv_fwd(x, w, torch.zeros(2, 16, 99, device="cuda"), 2, 16)        # wrong Lout
+    with pytest.raises(ValueError):
+        ops.conv_fwd(x.transpose(1, 2), w, torch.zeros(2, 16, 13, device="cuda"), 2, 16)  # not frame-contiguous
+    with pytest.raises(RuntimeError):
+        ops.adam_step(x.view(-1), x.view(-1), x.view(-1), x.view(-1), 0)        # step is 1-based

@@ -1,0 +1,452 @@
+// conv_igemm.hip -- the six 1-D convolution passes of the U-Net as three implicit-GEMM kernels on the
+// gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+//
+//   F ("forward-shaped"):  Y[b,m,t]  = sum_{q,j}               W[m][q][j] * act(X[b,q,s*t+j-p])
+//        = nn.Conv1d forward (model.py:77-78)            and nn.ConvTranspose1d dgrad
+//   T ("transposed"):      Y[b,m,tau] = sum_{q,j: s*i+j-p=tau} W[q][m][j] * act(X[b,q,i])
+//        = nn.ConvTranspose1d forward (model.py:88-102)  and nn.Conv1d dgrad
+//        computed in gather form: output phase phi = (tau+p) mod s only sees taps j = s*jj + phi, so the GEMM
+//        rows are (m,phi) pairs, K = (q,jj), N = (b,u) with tau = s*u + phi - p.  No col2im scatter, no atomics.
+//   G ("gradient of W"):   dW[m][q][j] = sum_{b,i} actP(P[b,m,i]) * actQ(Q[b,q,s*i+j-p])
+//        = wgrad of both (conv: P=dy, Q=x; convT: P=x, Q=dy); beta = 0 write (zero_grad folded in).
+//
+// Tiling (all three): 256 threads = 4 waves in a 2x2 grid, workgroup tile 128x128, wave tile 64x64 = 2x2 MFMA
+// 32x32 accumulators (64 VGPRs), BK = 16.  Operand tiles live in LDS K-contiguous ([row][BK] with an 80-B row
+// stride => conflict-free ds_read_b128); lane half h = lane>>5 owns k in [8h, 8h+8) of each BK slab, so one lane
+// fetches its 8 A (or B) values of a 32-row block with two ds_read_b128 instead of eight ds_read_b32 (the MFMA
+// only needs A and B to agree on which k each lane half carries).  Global -> register -> LDS double buffering
+// with one barrier per BK slab; activations / zero padding / im2col indexing are applied while staging, so the
+// (Leaky)ReLU in front of every conv (model.py:91,96,103) and torch.cat (model.py:113) are never materialised.
+// Each output element is produced by exactly one workgroup in a fixed k order: results are deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "phasegen.h"
+#include "pg_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, NT = 256;
+constexpr int LDT = BK + 4;               // floats per LDS row (80 B)
+constexpr int TILE = BM * LDT;            // floats per operand tile (10 KB)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct IgemmParams {
+    const float* x; long x_bs;       // B-operand source (F,T: input activations; G: the "Q" tensor)
+    const float* w;                  // F,T: weights (A operand)
+    const float* pt; long pt_bs;     // G: the "P" tensor (A operand), (B, M, LP)
+    float* y; long y_bs;             // F,T: output activations; G: dW
+    const float* add; long add_bs;   // optional epilogue addend (same shape as y)
+    const float* ref; long ref_bs;   // optional epilogue mask source (same shape as y)
+    int B, Q, M, Lx, Ly, k, s, p;    // Q: channels of x; M: output channels (F,T) / channels of P (G)
+    int act_x, act_p, mask_mode;
+    int U, u_off;                    // T: positions per phase, first u
+    int LP;                          // G: frames of P
+    int tilesM, tilesN;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == PG_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
+    if (act == PG_ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+__device__ __forceinline__ float act_grad(float v, int act) {
+    if (act == PG_ACT_LEAKY02) return v > 0.f ? 1.f : 0.2f;
+    if (act == PG_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+// XCD-aware, bijective remap of the linear workgroup id: hardware deals consecutive ids round-robin over the
+// 8 XCDs; give every XCD a contiguous run of tiles (same weight panel => private-L2 hits).  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, local = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+struct Acc { f32x16 c[2][2]; };
+
+// One BK=16 slab: 8 x ds_read_b128, then 8 k-pairs x 4 MFMA.
+__device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs,
+                                         int lane, int wm, int wn, Acc& acc) {
+    const int r = lane & 31, h = lane >> 5;
+    const float* ap = As + (wm * 64 + r) * LDT + h * 8;
+    const float* bp = Bs + (wn * 64 + r) * LDT + h * 8;
+    f32x4 a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a[i][0] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDT);
+        a[i][1] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDT + 4);
+        b[i][0] = *reinterpret_cast<const f32x4*>(bp + i * 32 * LDT);
+        b[i][1] = *reinterpret_cast<const f32x4*>(bp + i * 32 * LDT + 4);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const float a0 = a[0][kk >> 2][kk & 3], a1 = a[1][kk >> 2][kk & 3];
+        const float b0 = b[0][kk >> 2][kk & 3], b1 = b[1][kk >> 2][kk & 3];
+        acc.c[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.c[0][0], 0, 0, 0);
+        acc.c[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.c[0][1], 0, 0, 0);
+        acc.c[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.c[1][0], 0, 0, 0);
+        acc.c[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.c[1][1], 0, 0, 0);
+    }
+}
+
+// Register-staged tiles: each thread carries 2 x float4 of A and 2 x float4 of B per slab.
+struct Stage { f32x4 a[2], b[2]; };
+
+__device__ __forceinline__ void stage_store(float* As, float* Bs, const Stage& st, int tid) {
+    // A: thread -> (row = tid>>2 (+64), kgroup = tid&3);  B: thread -> (row = tid&127, kgroup = tid>>7 (+2))
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        *reinterpret_cast<f32x4*>(As + ((tid >> 2) + 64 * e) * LDT + (tid & 3) * 4) = st.a[e];
+        *reinterpret_cast<f32x4*>(Bs + (tid & 127) * LDT + ((tid >> 7) + 2 * e) * 4) = st.b[e];
+    }
+}
+
+// Epilogue value: optional addend, optional activation-derivative mask.
+__device__ __forceinline__ float epi(const IgemmParams& p, float v, long idx_add, long idx_ref) {
+    if (p.add) v += p.add[idx_add];
+    if (p.mask_mode) v *= act_grad(p.ref[idx_ref], p.mask_mode);
+    return v;
+}
+
+#define PG_MAINLOOP(LOAD_A, LOAD_B)                                                     \
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];                        \
+    Acc acc;                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;            \
+    Stage st;                                                                           \
+    const int nslab = (Ktot + BK - 1) / BK;                                             \
+    { const int k0 = 0; LOAD_A; LOAD_B; }                                               \
+    stage_store(lds, lds + TILE, st, tid);                                              \
+    __syncthreads();                                                                    \
+    for (int sl = 0; sl < nslab; ++sl) {                                                \
+        const int cur = sl & 1;                                                         \
+        const bool more = sl + 1 < nslab;                                               \
+        if (more) { const int k0 = (sl + 1) * BK; LOAD_A; LOAD_B; }                     \
+        mma_slab(lds + cur * 2 * TILE, lds + cur * 2 * TILE + TILE, lane, wm, wn, acc); \
+        if (more) stage_store(lds + (cur ^ 1) * 2 * TILE, lds + (cur ^ 1) * 2 * TILE + TILE, st, tid); \
+        __syncthreads();                                                                \
+    }
+
+// ------------------------------------------------------------------------------------------------------------
+// F kernel
+// ------------------------------------------------------------------------------------------------------------
+template <int KW, int S>
+__global__ __launch_bounds__(NT) void conv_f_kernel(const IgemmParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
+    const int kw = KW ? KW : p.k, s = S ? S : p.s;
+    const int Ktot = p.Q * kw, Ntot = p.B * p.Ly;
+    const bool avec = (Ktot & 3) == 0;
+
+    // B-operand (im2col) thread constants: one output position n per thread.
+    const int nB = n0 + (tid & 127);
+    const bool nvalid = nB < Ntot;
+    const int bB = nvalid ? nB / p.Ly : 0, tB = nvalid ? nB - bB * p.Ly : 0;
+    const float* xb = p.x + (long)bB * p.x_bs + (s * tB - p.p);
+    const int jlo = p.p - s * tB, jhi = p.Lx + p.p - s * tB;   // taps with 0 <= s*t+j-p < Lx
+    const int act = p.act_x;
+    const float* __restrict__ w = p.w;
+
+#define F_LOAD_A                                                                                   \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
+        const int m = m0 + (tid >> 2) + 64 * e, kk = k0 + (tid & 3) * 4;                           \
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                            \
+        if (m < p.M) {                                                                             \
+            const float* src = w + (long)m * Ktot + kk;                                            \
+            if (avec) { if (kk < Ktot) v = *reinterpret_cast<const f32x4*>(src); }                 \
+            else { _Pragma("unroll") for (int i = 0; i < 4; ++i) if (kk + i < Ktot) v[i] = src[i]; } \
+        }                                                                                          \
+        st.a[e] = v;                                                                               \
+    }
+#define F_LOAD_B                                                                                   \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
+        const int kk0 = k0 + ((tid >> 7) + 2 * e) * 4;                                             \
+        f32x4 v;                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+            const int kk = kk0 + i, q = kk / kw, j = kk - q * kw;                                  \
+            const bool ok = nvalid && kk < Ktot && j >= jlo && j < jhi;                            \
+            v[i] = ok ? act_apply(xb[(long)q * p.Lx + j], act) : 0.f;                              \
+        }                                                                                          \
+        st.b[e] = v;                                                                               \
+    }
+    PG_MAINLOOP(F_LOAD_A, F_LOAD_B)
+#undef F_LOAD_A
+#undef F_LOAD_B
+
+    // epilogue: acc reg r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (n >= Ntot) continue;
+        const int b = n / p.Ly, t = n - b * p.Ly;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) {
+                    const long off = (long)m * p.Ly + t;
+                    p.y[(long)b * p.y_bs + off] = epi(p, acc.c[i][j][r], (long)b * p.add_bs + off, (long)b * p.ref_bs + off);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// T kernel.  GEMM rows m' = o*s + phi, K = (q, jj) with KJ = ceil(k/s) taps per phase, N = (b, u).
+// ------------------------------------------------------------------------------------------------------------
+template <int KW, int S>
+__global__ __launch_bounds__(NT) void conv_t_kernel(const IgemmParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
+    const int kw = KW ? KW : p.k, s = S ? S : p.s;
+    const int KJ = (kw + s - 1) / s;
+    const int Ktot = p.Q * KJ, Ntot = p.B * p.U, Mrows = p.M * s;
+
+    const int nB = n0 + (tid & 127);
+    const bool nvalid = nB < Ntot;
+    const int bB = nvalid ? nB / p.U : 0, uB = (nvalid ? nB - bB * p.U : 0) + p.u_off;
+    const float* xb = p.x + (long)bB * p.x_bs + uB;
+    const int act = p.act_x;
+    const float* __restrict__ w = p.w;
+    const long wq = (long)p.M * kw;           // weight stride between input channels q
+
+#define T_LOAD_A                                                                                   \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
+        const int mr = m0 + (tid >> 2) + 64 * e, o = mr / s, phi = mr - o * s;                     \
+        const int kk0 = k0 + (tid & 3) * 4;                                                        \
+        f32x4 v;                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+            const int kk = kk0 + i, q = kk / KJ, jj = kk - q * KJ, j = s * jj + phi;               \
+            const bool ok = mr < Mrows && kk < Ktot && j < kw;                                     \
+            v[i] = ok ? w[q * wq + (long)o * kw + j] : 0.f;                                        \
+        }                                                                                          \
+        st.a[e] = v;                                                                               \
+    }
+#define T_LOAD_B                                                                                   \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
+        const int kk0 = k0 + ((tid >> 7) + 2 * e) * 4;                                             \
+        f32x4 v;                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+            const int kk = kk0 + i, q = kk / KJ, jj = kk - q * KJ, pos = uB - jj;                  \
+            const bool ok = nvalid && kk < Ktot && pos >= 0 && pos < p.Lx;                         \
+            v[i] = ok ? act_apply(xb[(long)q * p.Lx - jj], act) : 0.f;                             \
+        }                                                                                          \
+        st.b[e] = v;                                                                               \
+    }
+    PG_MAINLOOP(T_LOAD_A, T_LOAD_B)
+#undef T_LOAD_A
+#undef T_LOAD_B
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (n >= Ntot) continue;
+        const int b = n / p.U, u = n - b * p.U + p.u_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int o = mr / s, phi = mr - o * s, tau = s * u + phi - p.p;
+                if (mr < Mrows && tau >= 0 && tau < p.Ly) {
+                    const long off = (long)o * p.Ly + tau;
+                    p.y[(long)b * p.y_bs + off] = epi(p, acc.c[i][j][r], (long)b * p.add_bs + off, (long)b * p.ref_bs + off);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// G kernel.  dW[m][(q,j)] = sum over kk = (b,i) of actP(P[b,m,i]) * actQ(Q[b,q,s*i+j-p]);  Q tensor is p.x.
+// ------------------------------------------------------------------------------------------------------------
+template <int KW, int S>
+__global__ __launch_bounds__(NT) void conv_g_kernel(const IgemmParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
+    const int kw = KW ? KW : p.k, s = S ? S : p.s;
+    const int Ktot = p.B * p.LP, Ntot = p.Q * kw;
+
+    // B operand: one (q,j) per thread
+    const int nB = n0 + (tid & 127);
+    const bool nvalid = nB < Ntot;
+    const int qB = nvalid ? nB / kw : 0, jB = nvalid ? nB - qB * kw : 0;
+    const float* xq = p.x + (long)qB * p.Lx + (jB - p.p);
+    const int actq = p.act_x, actp = p.act_p;
+    const float* __restrict__ pt = p.pt;
+    // running (b, i) decode of this thread's first kk of the slab, for A (kgroup tid&3) and B (kgroups tid>>7, +2)
+    int kA = (tid & 3) * 4, bA = kA / p.LP, iA = kA - bA * p.LP;
+    int kB0 = (tid >> 7) * 4, bB0 = kB0 / p.LP, iB0 = kB0 - bB0 * p.LP;
+    int kB1 = kB0 + 8, bB1 = kB1 / p.LP, iB1 = kB1 - bB1 * p.LP;
+    int kprev = 0;
+
+#define G_ADVANCE(bb, ii, d) { ii += (d); while (ii >= p.LP) { ii -= p.LP; ++bb; } }
+#define G_LOAD_A                                                                                   \
+    { const int d = k0 - kprev; kprev = k0;                                                        \
+      G_ADVANCE(bA, iA, d) G_ADVANCE(bB0, iB0, d) G_ADVANCE(bB1, iB1, d) }                         \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
+        const int m = m0 + (tid >> 2) + 64 * e;                                                    \
+        int bb = bA, ii = iA; f32x4 v;                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+            const bool ok = m < p.M && bb < p.B;                                                   \
+            v[i] = ok ? act_apply(pt[(long)bb * p.pt_bs + (long)m * p.LP + ii], actp) : 0.f;       \
+            if (++ii == p.LP) { ii = 0; ++bb; }                                                    \
+        }                                                                                          \
+        st.a[e] = v;                                                                               \
+    }
+#define G_LOAD_B                                                                                   \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
+        int bb = e ? bB1 : bB0, ii = e ? iB1 : iB0; f32x4 v;                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+            const int pos = s * ii + jB - p.p;                                                     \
+            const bool ok = nvalid && bb < p.B && pos >= 0 && pos < p.Lx;                          \
+            v[i] = ok ? act_apply(xq[(long)bb * p.x_bs + s * ii], actq) : 0.f;                     \
+            if (++ii == p.LP) { ii = 0; ++bb; }                                                    \
+        }                                                                                          \
+        st.b[e] = v;                                                                               \
+    }
+    PG_MAINLOOP(G_LOAD_A, G_LOAD_B)
+#undef G_LOAD_A
+#undef G_LOAD_B
+#undef G_ADVANCE
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (n >= Ntot) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) p.y[(long)m * Ntot + n] = acc.c[i][j][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+enum Kind { KIND_F, KIND_T, KIND_G };
+
+template <int KW, int S>
+hipError_t launch_kind(Kind kind, const IgemmParams& p, int grid, hipStream_t st) {
+    switch (kind) {
+        case KIND_F: hipLaunchKernelGGL((conv_f_kernel<KW, S>), dim3(grid), dim3(NT), 0, st, p); break;
+        case KIND_T: hipLaunchKernelGGL((conv_t_kernel<KW, S>), dim3(grid), dim3(NT), 0, st, p); break;
+        case KIND_G: hipLaunchKernelGGL((conv_g_kernel<KW, S>), dim3(grid), dim3(NT), 0, st, p); break;
+    }
+    return hipGetLastError();
+}
+
+int launch(Kind kind, IgemmParams& p, long rows, long cols, hipStream_t st) {
+    p.tilesM = (int)((rows + BM - 1) / BM);
+    p.tilesN = (int)((cols + BN - 1) / BN);
+    const long grid = (long)p.tilesM * p.tilesN;
+    if (grid <= 0 || grid > 0x7fffffffL) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");
+    hipError_t e;
+    if (p.k == 32 && p.s == 2) e = launch_kind<32, 2>(kind, p, (int)grid, st);
+    else if (p.k == 8 && p.s == 1) e = launch_kind<8, 1>(kind, p, (int)grid, st);
+    else if (p.k == 8 && p.s == 2) e = launch_kind<8, 2>(kind, p, (int)grid, st);
+    else if (p.k == 4 && p.s == 2) e = launch_kind<4, 2>(kind, p, (int)grid, st);
+    else if (p.k == 5 && p.s == 2) e = launch_kind<5, 2>(kind, p, (int)grid, st);
+    else e = launch_kind<0, 0>(kind, p, (int)grid, st);
+    if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
+    return PG_OK;
+}
+
+int check_geom(const pg_conv_args* a, bool transposed) {
+    if (!a) return pg_fail(PG_ERR_NULL, "conv: null args");
+    if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->Lin <= 0 || a->Lout <= 0 || a->k <= 0 || a->stride <= 0 || a->pad < 0)
+        return pg_fail(PG_ERR_SHAPE, "conv: non-positive dimension");
+    const long lo = transposed ? (long)(a->Lin - 1) * a->stride - 2L * a->pad + a->k
+                               : ((long)a->Lin + 2L * a->pad - a->k) / a->stride + 1;
+    if (lo != a->Lout) return pg_fail(PG_ERR_SHAPE, "conv: Lout inconsistent with Lin/k/stride/pad");
+    if ((long)a->B * (long)(a->Cin > a->Cout ? a->Cin : a->Cout) * (long)(a->Lin > a->Lout ? a->Lin : a->Lout) > 0x7fffffffL)
+        return pg_fail(PG_ERR_SHAPE, "conv: tensor exceeds 2^31 elements");
+    return PG_OK;
+}
+
+}  // namespace
+
+// nn.Conv1d forward: F kernel with M = Cout, Q = Cin.
+extern "C" int pg_conv1d_fwd(const pg_conv_args* a, void* stream) {
+    if (int e = check_geom(a, false)) return e;
+    if (!a->x || !a->w || !a->y) return pg_fail(PG_ERR_NULL, "conv1d_fwd: x, w, y required");
+    IgemmParams p = {};
+    p.x = a->x; p.x_bs = a->x_bs; p.w = a->w; p.y = a->y; p.y_bs = a->y_bs;
+    p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.Ly = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    p.act_x = a->x_act;
+    return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (hipStream_t)stream);
+}
+
+// nn.ConvTranspose1d dgrad: dx[b,c,i] = sum_{o,j} w[c][o][j] dy[b,o,s*i+j-p]  -> F kernel with M = Cin, Q = Cout.
+extern "C" int pg_convt1d_dgrad(const pg_conv_args* a, void* stream) {
+    if (int e = check_geom(a, true)) return e;
+    if (!a->dy || !a->w || !a->dx) return pg_fail(PG_ERR_NULL, "convt1d_dgrad: dy, w, dx required");
+    IgemmParams p = {};
+    p.x = a->dy; p.x_bs = a->dy_bs; p.w = a->w; p.y = a->dx; p.y_bs = a->dx_bs;
+    p.add = a->dx_add; p.add_bs = a->dx_add_bs; p.ref = a->dx_ref; p.ref_bs = a->dx_ref_bs;
+    p.mask_mode = a->dx_ref ? a->dx_mask : 0;
+    p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.Ly = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (hipStream_t)stream);
+}
+
+static int launch_t(IgemmParams& p, hipStream_t st) {
+    // tau = s*u + phi - p >= 0 for some phi  <=>  u >= floor(p/s) at the latest; tau <= Ly-1 => u <= (Ly-1+p)/s
+    p.u_off = p.p / p.s;
+    const int u_max = (p.Ly - 1 + p.p) / p.s;
+    p.U = u_max - p.u_off + 1;
+    if (p.U <= 0) return pg_fail(PG_ERR_SHAPE, "convT: empty output");
+    return launch(KIND_T, p, (long)p.M * p.s, (long)p.B * p.U, st);
+}
+
+// nn.ConvTranspose1d forward: T kernel with M = Cout, Q = Cin.
+extern "C" int pg_convt1d_fwd(const pg_conv_args* a, void* stream) {
+    if (int e = check_geom(a, true)) return e;
+    if (!a->x || !a->w || !a->y) return pg_fail(PG_ERR_NULL, "convt1d_fwd: x, w, y required");
+    IgemmParams p = {};
+    p.x = a->x; p.x_bs = a->x_bs; p.w = a->w; p.y = a->y; p.y_bs = a->y_bs;
+    p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.Ly = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    p.act_x = a->x_act;
+    return launch_t(p, (hipStream_t)stream);
+}
+
+// nn.Conv1d dgrad: dx[b,c,u] = sum_{o,j,t: s*t+j-p=u} w[o][c][j] dy[b,o,t]  -> T kernel with M = Cin, Q = Cout.
+extern "C" int pg_conv1d_dgrad(const pg_conv_args* a, void* stream) {
+    if (int e = check_geom(a, false)) return e;
+    if (!a->dy || !a->w || !a->dx) return pg_fail(PG_ERR_NULL, "conv1d_dgrad: dy, w, dx required");
+    IgemmParams p = {};
+    p.x = a->dy; p.x_bs = a->dy_bs; p.w = a->w; p.y = a->dx; p.y_bs = a->dx_bs;
+    p.add = a->dx_add; p.add_bs = a->dx_add_bs; p.ref = a->dx_ref; p.ref_bs = a->dx_ref_bs;
+    p.mask_mode = a->dx_ref ? a->dx_mask : 0;
+    p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.Ly = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    return launch_t(p, (hipStream_t)stream);
+}
+
+// nn.Conv1d wgrad: dw[o][c][j] = sum_{b,t} dy[b,o,t] act(x)[b,c,s*t+j-p]  -> G with P = dy (M = Cout), Q = x.
+extern "C" int pg_conv1d_wgrad(const pg_conv_args* a, void* stream) {
+    if (int e = check_geom(a, false)) return e;
+    if (!a->dy || !a->x || !a->dw) return pg_fail(PG_ERR_NULL, "conv1d_wgrad: dy, x, dw required");
+    IgemmParams p = {};
+    p.pt = a->dy; p.pt_bs = a->dy_bs; p.LP = a->Lout; p.act_p = PG_ACT_NONE;
+    p.x = a->x; p.x_bs = a->x_bs; p.act_x = a->x_act; p.y = a->dw;
+    p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    return launch(KIND_G, p, p.M, (long)p.Q * p.k, (hipStream_t)stream);
+}
+
+// nn.ConvTranspose1d wgrad: dw[c][o][j] = sum_{b,i} act(x)[b,c,i] dy[b,o,s*i+j-p]  -> G with P = x (M = Cin), Q = dy.
+extern "C" int pg_convt1d_wgrad(const pg_conv_args* a, void* stream) {
+    if (int e = check_geom(a, true)) return e;
+    if (!a->dy || !a->x || !a->dw) return pg_fail(PG_ERR_NULL, "convt1d_wgrad: dy, x, dw required");
+    IgemmParams p = {};
+    p.pt = a->x; p.pt_bs = a->x_bs; p.LP = a->Lin; p.act_p = a->x_act;
+    p.x = a->dy; p.x_bs = a->dy_bs; p.act_x = PG_ACT_NONE; p.y = a->dw;
+    p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    return launch(KIND_G, p, p.M, (long)p.Q * p.k, (hipStream_t)stream);
+}

@@ -1,0 +1,24 @@
+// pg_common.h -- internal helpers shared by the libphasegen translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+// Records `msg` as the calling thread's last error and returns `code` (see pg_last_error_string()).
+int pg_fail(int code, const char* msg);
+
+// Wave(64)-level and block-level sum reductions (wavefront shuffles, then 4..16 partials through LDS).
+__device__ __forceinline__ float pg_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// All threads get the block-wide sum.  `scratch` = at least 16 floats of LDS; safe to reuse after return.
+__device__ __forceinline__ float pg_block_sum(float v, float* scratch) {
+    v = pg_wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}

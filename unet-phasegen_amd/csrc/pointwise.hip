@@ -1,0 +1,239 @@
+// pointwise.hip -- the HBM-bound side of the path: train-mode BatchNorm (forward / backward), the fused
+// cos/sin/magnitude loss with its gradient, Adam over the flat parameter arena, and the polar transform.
+// All are streaming kernels: coalesced frame-contiguous reads, wavefront shuffle reductions, no atomics
+// (every reduction has a fixed order => bit-reproducible run to run).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "phasegen.h"
+#include "pg_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm, one workgroup per channel.  Tensor element (b, c, l) = base[b*bs + c*L + l].
+// model.py:81,83 (nn.BatchNorm on (B, C, L)): mean / biased var over (B, L), eps inside the sqrt,
+// running_var gets the unbiased variance, momentum 0.1.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const pg_bn_args a) {
+    __shared__ float scratch[16];
+    const int c = blockIdx.x, n = a.B * a.L;
+    const float* xc = a.x + (long)c * a.L;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int b = e / a.L, l = e - b * a.L;
+        s += xc[(long)b * a.x_bs + l];
+    }
+    const float mean = pg_block_sum(s, scratch) / (float)n;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int b = e / a.L, l = e - b * a.L;
+        const float d = xc[(long)b * a.x_bs + l] - mean;
+        q += d * d;
+    }
+    const float var = pg_block_sum(q, scratch) / (float)n;
+    const float invstd = 1.0f / sqrtf(var + a.eps);
+    const float g = a.gamma[c], be = a.beta[c];
+    float* yc = a.y + (long)c * a.L;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int b = e / a.L, l = e - b * a.L;
+        yc[(long)b * a.y_bs + l] = (xc[(long)b * a.x_bs + l] - mean) * invstd * g + be;
+    }
+    if (threadIdx.x == 0) {
+        a.save_mean[c] = mean;
+        a.save_invstd[c] = invstd;
+        if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+        if (a.running_var) {
+            const float unbiased = var * ((float)n / (float)(n > 1 ? n - 1 : 1));
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unbiased;
+        }
+    }
+}
+
+// dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat));  dgamma = sum(dy * xhat);  dbeta = sum(dy)
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const pg_bn_args a) {
+    __shared__ float scratch[16];
+    const int c = blockIdx.x, n = a.B * a.L;
+    const float* xc = a.x + (long)c * a.L;
+    const float* dyc = a.dy + (long)c * a.L;
+    const float mean = a.save_mean[c], invstd = a.save_invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int b = e / a.L, l = e - b * a.L;
+        const float dy = dyc[(long)b * a.dy_bs + l];
+        s1 += dy;
+        s2 += dy * (xc[(long)b * a.x_bs + l] - mean) * invstd;
+    }
+    const float sum_dy = pg_block_sum(s1, scratch);
+    const float sum_dy_xhat = pg_block_sum(s2, scratch);
+    const float k = a.gamma[c] * invstd, m1 = sum_dy / (float)n, m2 = sum_dy_xhat / (float)n;
+    float* dxc = a.dx + (long)c * a.L;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int b = e / a.L, l = e - b * a.L;
+        const float xhat = (xc[(long)b * a.x_bs + l] - mean) * invstd;
+        dxc[(long)b * a.dx_bs + l] = k * (dyc[(long)b * a.dy_bs + l] - m1 - xhat * m2);
+    }
+    if (threadIdx.x == 0) {
+        a.dgamma[c] = sum_dy_xhat;
+        a.dbeta[c] = sum_dy;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Loss (train.py:45-60) fused with d loss / d pred.  One thread per (b, c, l); stage 1 leaves 3 partial sums
+// per workgroup in the workspace, stage 2 (one workgroup) adds them in double in a fixed order.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LOSS_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(const pg_loss_args a, float* partial) {
+    __shared__ float scratch[16];
+    const long CL = (long)a.C * a.L, N = (long)a.B * CL;
+    const float scale = 2.0f / (float)N;
+    float s_cos = 0.f, s_sin = 0.f, s_mag = 0.f;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < N; e += (long)gridDim.x * blockDim.x) {
+        const long b = e / CL, r = e - b * CL;
+        const float ph = a.pred[b * 2 * CL + r], mh = a.pred[b * 2 * CL + CL + r];
+        const float m = a.batch[b * 2 * CL + r], th = a.batch[b * 2 * CL + CL + r];
+        float sp, cp, st, ct;
+        sincosf(ph, &sp, &cp);
+        sincosf(th, &st, &ct);
+        const float dc = cp - ct, ds = sp - st, dm = mh - m;
+        s_cos += dc * dc; s_sin += ds * ds; s_mag += dm * dm;
+        if (a.dpred) {
+            // autograd of MSE(cos p, cos th) + MSE(sin p, sin th):  2/N * (dc * -sin p + ds * cos p)
+            a.dpred[b * 2 * CL + r] = scale * (ds * cp - dc * sp);
+            a.dpred[b * 2 * CL + CL + r] = a.mag_weight * scale * dm;
+        }
+    }
+    s_cos = pg_block_sum(s_cos, scratch);
+    s_sin = pg_block_sum(s_sin, scratch);
+    s_mag = pg_block_sum(s_mag, scratch);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 3 + 0] = s_cos; partial[blockIdx.x * 3 + 1] = s_sin; partial[blockIdx.x * 3 + 2] = s_mag;
+    }
+}
+
+__global__ __launch_bounds__(64) void loss_final_kernel(const float* partial, int nblocks, double n, float mag_weight, float* losses) {
+    if (threadIdx.x == 0) {
+        double c = 0, s = 0, m = 0;
+        for (int i = 0; i < nblocks; ++i) { c += partial[i * 3]; s += partial[i * 3 + 1]; m += partial[i * 3 + 2]; }
+        const float cos_l = (float)(c / n), sin_l = (float)(s / n), mag_l = (float)(m / n);
+        const float ang = cos_l + sin_l;
+        losses[0] = ang + mag_l * mag_weight; losses[1] = ang; losses[2] = mag_l;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults, single-tensor path of torch 2.x): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g g;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  28 B of HBM traffic per parameter.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float omb1, float b2, float omb2,
+                                         float step_size, float bc2_sqrt, float eps, float gs) {
+    g *= gs;
+    m = m + omb1 * (g - m);
+    v = v * b2 + omb2 * (g * g);
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float omb1, float b2, float omb2,
+                                                   float step_size, float bc2_sqrt, float eps, float gs) {
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = pp[k], b = mm[k], c = vv[k];
+            adam_one(a, gg[k], b, c, omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
+            pp[k] = a; mm[k] = b; vv[k] = c;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp; reinterpret_cast<f32x4*>(m)[i] = mm; reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        adam_one(p[i], g[i], m[i], v[i], omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// data.py:39-47: [re; im] -> [log1p(|z|); angle(z)], 16 B of traffic per bin-frame.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void polar_kernel(const float* __restrict__ in, float* __restrict__ out, long n_items, long inner) {
+    const long total = n_items * inner;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long it = e / inner, r = e - it * inner;
+        const float re = in[it * 2 * inner + r], im = in[it * 2 * inner + inner + r];
+        out[it * 2 * inner + r] = log1pf(hypotf(re, im));
+        out[it * 2 * inner + inner + r] = atan2f(im, re);
+    }
+}
+
+int launch_ok(const char* what) {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PG_OK : pg_fail((int)e, what);
+}
+
+int bn_check(const pg_bn_args* a) {
+    if (!a) return pg_fail(PG_ERR_NULL, "bn: null args");
+    if (a->B <= 0 || a->C <= 0 || a->L <= 0) return pg_fail(PG_ERR_SHAPE, "bn: non-positive dimension");
+    if ((long)a->B * a->L > 0x7fffffffL) return pg_fail(PG_ERR_SHAPE, "bn: B*L too large");
+    return PG_OK;
+}
+
+}  // namespace
+
+extern "C" int pg_bn_fwd(const pg_bn_args* a, void* stream) {
+    if (int e = bn_check(a)) return e;
+    if (!a->x || !a->y || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd)
+        return pg_fail(PG_ERR_NULL, "bn_fwd: x, y, gamma, beta, save_mean, save_invstd required");
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
+    return launch_ok("bn_fwd launch failed");
+}
+
+extern "C" int pg_bn_bwd(const pg_bn_args* a, void* stream) {
+    if (int e = bn_check(a)) return e;
+    if (!a->x || !a->dy || !a->dx || !a->gamma || !a->save_mean || !a->save_invstd || !a->dgamma || !a->dbeta)
+        return pg_fail(PG_ERR_NULL, "bn_bwd: x, dy, dx, gamma, save_mean, save_invstd, dgamma, dbeta required");
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
+    return launch_ok("bn_bwd launch failed");
+}
+
+extern "C" int64_t pg_workspace_bytes_loss(const pg_loss_args*) { return (int64_t)LOSS_BLOCKS * 3 * sizeof(float); }
+
+extern "C" int pg_loss_fwd_bwd(const pg_loss_args* a, void* stream) {
+    if (!a || !a->pred || !a->batch || !a->losses || !a->workspace) return pg_fail(PG_ERR_NULL, "loss: pred, batch, losses, workspace required");
+    if (a->B <= 0 || a->C <= 0 || a->L <= 0) return pg_fail(PG_ERR_SHAPE, "loss: non-positive dimension");
+    if (a->workspace_bytes < pg_workspace_bytes_loss(a)) return pg_fail(PG_ERR_WORKSPACE, "loss: workspace too small");
+    const long N = (long)a->B * a->C * a->L;
+    int blocks = (int)((N + 255) / 256); if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
+    float* partial = (float*)a->workspace;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, partial);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, blocks, (double)N, a->mag_weight, a->losses);
+    return launch_ok("loss launch failed");
+}
+
+extern "C" int pg_adam_step(const pg_adam_args* a, void* stream) {
+    if (!a || !a->p || !a->g || !a->m || !a->v) return pg_fail(PG_ERR_NULL, "adam: p, g, m, v required");
+    if (a->n <= 0) return PG_OK;
+    if (a->step < 1) return pg_fail(PG_ERR_SHAPE, "adam: step is 1-based");
+    if (((uintptr_t)a->p | (uintptr_t)a->g | (uintptr_t)a->m | (uintptr_t)a->v) & 15) return pg_fail(PG_ERR_ALIGN, "adam: pointers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow(a->beta1, a->step), bc2 = 1.0 - pow(a->beta2, a->step);
+    const float step_size = (float)(a->lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    long blocks = ((a->n >> 2) + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v, (long)a->n,
+                       (float)(1.0 - a->beta1), (float)a->beta2, (float)(1.0 - a->beta2), step_size, bc2_sqrt, (float)a->eps,
+                       (float)a->grad_scale);
+    return launch_ok("adam launch failed");
+}
+
+extern "C" int pg_polar(const pg_polar_args* a, void* stream) {
+    if (!a || !a->in || !a->out) return pg_fail(PG_ERR_NULL, "polar: in, out required");
+    if (a->n_items <= 0 || a->inner <= 0) return pg_fail(PG_ERR_SHAPE, "polar: non-positive size");
+    long blocks = (a->n_items * a->inner + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(polar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->in, a->out, (long)a->n_items, (long)a->inner);
+    return launch_ok("polar launch failed");
+}

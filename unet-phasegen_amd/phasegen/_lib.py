@@ -1,0 +1,117 @@
+"""ctypes binding of libphasegen.so (the C ABI declared in include/phasegen.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the shared object is missing or a
+symbol cannot be resolved, importing the ops raises; if a call returns non-zero, ``check`` raises RuntimeError
+with ``pg_last_error_string()`` (the reference's error convention is Python exceptions).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphasegen.so")
+
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("Lin", C.c_int32), ("Lout", C.c_int32),
+                ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("x", C.c_void_p), ("x_bs", C.c_int64), ("x_act", C.c_int32), ("_pad0", C.c_int32),
+                ("w", C.c_void_p),
+                ("y", C.c_void_p), ("y_bs", C.c_int64),
+                ("dy", C.c_void_p), ("dy_bs", C.c_int64),
+                ("dx", C.c_void_p), ("dx_bs", C.c_int64),
+                ("dx_add", C.c_void_p), ("dx_add_bs", C.c_int64),
+                ("dx_ref", C.c_void_p), ("dx_ref_bs", C.c_int64),
+                ("dx_mask", C.c_int32), ("_pad1", C.c_int32),
+                ("dw", C.c_void_p)]
+
+
+class BnArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float),
+                ("x", C.c_void_p), ("x_bs", C.c_int64), ("y", C.c_void_p), ("y_bs", C.c_int64),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("dy", C.c_void_p), ("dy_bs", C.c_int64), ("dx", C.c_void_p), ("dx_bs", C.c_int64),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
+class LossArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("mag_weight", C.c_float),
+                ("pred", C.c_void_p), ("batch", C.c_void_p), ("dpred", C.c_void_p), ("losses", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("grad_scale", C.c_double), ("step", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class StftArgs(C.Structure):
+    _fields_ = [("n_signals", C.c_int32), ("n_samples", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32),
+                ("n_frames", C.c_int32), ("polar", C.c_int32), ("y", C.c_void_p), ("out", C.c_void_p)]
+
+
+class PolarArgs(C.Structure):
+    _fields_ = [("n_items", C.c_int64), ("inner", C.c_int64), ("inp", C.c_void_p), ("out", C.c_void_p)]
+
+
+class IstftArgs(C.Structure):
+    _fields_ = [("n_signals", C.c_int32), ("bins", C.c_int32), ("n_frames", C.c_int32), ("hop", C.c_int32),
+                ("mode", C.c_int32), ("normalize", C.c_int32),
+                ("a", C.c_void_p), ("a_bs", C.c_int64), ("b", C.c_void_p), ("b_bs", C.c_int64),
+                ("audio", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
+# every symbol include/phasegen.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "pg_conv1d_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "pg_conv1d_dgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "pg_conv1d_wgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "pg_convt1d_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "pg_convt1d_dgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "pg_convt1d_wgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "pg_bn_fwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),
+    "pg_bn_bwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),
+    "pg_workspace_bytes_loss": (C.c_int64, [C.POINTER(LossArgs)]),
+    "pg_loss_fwd_bwd": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
+    "pg_adam_step": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
+    "pg_stft": (C.c_int, [C.POINTER(StftArgs), C.c_void_p]),
+    "pg_stft_frame_index": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pg_polar": (C.c_int, [C.POINTER(PolarArgs), C.c_void_p]),
+    "pg_workspace_bytes_istft": (C.c_int64, [C.POINTER(IstftArgs)]),
+    "pg_istft": (C.c_int, [C.POINTER(IstftArgs), C.c_void_p]),
+    "pg_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "pg_version": (C.c_int, []),
+    "pg_last_error_string": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libphasegen.so and bind every declared symbol.  Raises if anything is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C unet-phasegen_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the phasegen hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().pg_last_error_string()
+        raise RuntimeError(f"libphasegen {what} failed: {msg.decode() if msg else rc}")

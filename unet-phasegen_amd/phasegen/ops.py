@@ -1,0 +1,244 @@
+"""Thin host-side wrappers: torch (ROCm) tensors in, one libphasegen C-ABI call out.
+
+PyTorch is plumbing here (device memory + the current HIP stream); every op below is a hand-written gfx950
+kernel behind ``include/phasegen.h``.  Activation tensors are (B, channels, frames) views whose frame stride is 1
+and channel stride is ``frames``; the batch stride is free, so the two halves of a U-Net concat buffer are passed
+as plain slices ``buf[:, :n]`` / ``buf[:, n:]`` without a copy.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401  (re-exported)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _act3(t, name):
+    """(ptr, batch_stride) of a (B, C, L) fp32 device view with L-contiguous channels."""
+    if t is None:
+        return None, 0
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3):
+        raise ValueError(f"{name}: expected a 3-D float32 device tensor, got {tuple(t.shape)} {t.dtype} {t.device}")
+    B, Cc, L = t.shape
+    if t.stride(2) != 1 or (Cc > 1 and t.stride(1) != L):
+        raise ValueError(f"{name}: frames must be contiguous and channel stride == frames (strides {t.stride()})")
+    return t.data_ptr(), (t.stride(0) if B > 1 else Cc * L)
+
+
+def _dense(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous float32 device tensor")
+    return t.data_ptr()
+
+
+def conv_out_len(Lin, k, s, p):
+    return (Lin + 2 * p - k) // s + 1
+
+
+def convt_out_len(Lin, k, s, p):
+    return (Lin - 1) * s - 2 * p + k
+
+
+def _conv_args(transposed, B, Cin, Cout, Lin, k, s, p):
+    a = _lib.ConvArgs()
+    a.B, a.Cin, a.Cout, a.Lin, a.k, a.stride, a.pad = B, Cin, Cout, Lin, k, s, p
+    a.Lout = convt_out_len(Lin, k, s, p) if transposed else conv_out_len(Lin, k, s, p)
+    return a
+
+
+def _geom(transposed, w, k=None):
+    if transposed:
+        Cin, Cout, kk = w.shape
+    else:
+        Cout, Cin, kk = w.shape
+    return Cin, Cout, kk
+
+
+def conv_fwd(x, w, y, stride, pad, x_act=ACT_NONE, transposed=False):
+    """y = conv(act(x), w) (nn.Conv1d, model.py:77) or conv_transpose (model.py:88) -- writes into ``y``."""
+    Cin, Cout, k = _geom(transposed, w)
+    B, _, Lin = x.shape
+    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad)
+    if tuple(x.shape) != (B, Cin, Lin) or tuple(y.shape) != (B, Cout, a.Lout):
+        raise ValueError(f"conv_fwd: shapes x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)} inconsistent (Lout {a.Lout})")
+    a.x, a.x_bs = _act3(x, "x")
+    a.y, a.y_bs = _act3(y, "y")
+    a.w = _dense(w, "w")
+    a.x_act = x_act
+    lib = _lib.load()
+    fn = lib.pg_convt1d_fwd if transposed else lib.pg_conv1d_fwd
+    _lib.check(fn(C.byref(a), _stream()), "convt1d_fwd" if transposed else "conv1d_fwd")
+    return y
+
+
+def conv_dgrad(dy, w, dx, stride, pad, transposed=False, add=None, ref=None, mask=ACT_NONE):
+    """dx = dgrad(dy, w) [+ add] [* act'(ref)] -- grad wrt the tensor the forward op read."""
+    Cin, Cout, k = _geom(transposed, w)
+    B, _, Lin = dx.shape
+    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad)
+    if tuple(dy.shape) != (B, Cout, a.Lout) or tuple(dx.shape) != (B, Cin, Lin):
+        raise ValueError(f"conv_dgrad: shapes dy{tuple(dy.shape)} w{tuple(w.shape)} dx{tuple(dx.shape)} inconsistent")
+    a.dy, a.dy_bs = _act3(dy, "dy")
+    a.dx, a.dx_bs = _act3(dx, "dx")
+    a.w = _dense(w, "w")
+    if add is not None:
+        if add.shape != dx.shape:
+            raise ValueError("conv_dgrad: add must have dx's shape")
+        a.dx_add, a.dx_add_bs = _act3(add, "add")
+    if ref is not None:
+        if ref.shape != dx.shape:
+            raise ValueError("conv_dgrad: ref must have dx's shape")
+        a.dx_ref, a.dx_ref_bs = _act3(ref, "ref")
+        a.dx_mask = mask
+    lib = _lib.load()
+    fn = lib.pg_convt1d_dgrad if transposed else lib.pg_conv1d_dgrad
+    _lib.check(fn(C.byref(a), _stream()), "dgrad")
+    return dx
+
+
+def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False):
+    """dw = wgrad(act(x), dy), overwriting ``dw`` (same layout as the weight)."""
+    Cin, Cout, k = _geom(transposed, dw)
+    B, _, Lin = x.shape
+    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad)
+    if tuple(x.shape) != (B, Cin, Lin) or tuple(dy.shape) != (B, Cout, a.Lout):
+        raise ValueError(f"conv_wgrad: shapes x{tuple(x.shape)} dy{tuple(dy.shape)} dw{tuple(dw.shape)} inconsistent")
+    a.x, a.x_bs = _act3(x, "x")
+    a.dy, a.dy_bs = _act3(dy, "dy")
+    a.dw = _dense(dw, "dw")
+    a.x_act = x_act
+    lib = _lib.load()
+    fn = lib.pg_convt1d_wgrad if transposed else lib.pg_conv1d_wgrad
+    _lib.check(fn(C.byref(a), _stream()), "wgrad")
+    return dw
+
+
+def bn_fwd(x, y, gamma, beta, save_mean, save_invstd, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    a = _lib.BnArgs()
+    a.B, a.C, a.L = x.shape
+    a.eps, a.momentum = eps, momentum
+    a.x, a.x_bs = _act3(x, "x")
+    a.y, a.y_bs = _act3(y, "y")
+    a.gamma, a.beta = _dense(gamma, "gamma"), _dense(beta, "beta")
+    a.save_mean, a.save_invstd = _dense(save_mean, "save_mean"), _dense(save_invstd, "save_invstd")
+    if running_mean is not None:
+        a.running_mean, a.running_var = _dense(running_mean, "running_mean"), _dense(running_var, "running_var")
+    _lib.check(_lib.load().pg_bn_fwd(C.byref(a), _stream()), "bn_fwd")
+    return y
+
+
+def bn_bwd(x, dy, dx, gamma, save_mean, save_invstd, dgamma, dbeta):
+    a = _lib.BnArgs()
+    a.B, a.C, a.L = x.shape
+    a.x, a.x_bs = _act3(x, "x")
+    a.dy, a.dy_bs = _act3(dy, "dy")
+    a.dx, a.dx_bs = _act3(dx, "dx")
+    a.gamma = _dense(gamma, "gamma")
+    a.save_mean, a.save_invstd = _dense(save_mean, "save_mean"), _dense(save_invstd, "save_invstd")
+    a.dgamma, a.dbeta = _dense(dgamma, "dgamma"), _dense(dbeta, "dbeta")
+    _lib.check(_lib.load().pg_bn_bwd(C.byref(a), _stream()), "bn_bwd")
+    return dx
+
+
+_loss_ws = {}
+
+
+def loss_fwd_bwd(pred, batch, dpred=None, losses=None, mag_weight=0.2):
+    """train.py:45-60 fused with its gradient.  Returns the 3-float device tensor [loss, ang, mag]."""
+    B, C2, L = pred.shape
+    Cc = C2 // 2
+    if tuple(batch.shape) != (B, 2, Cc, L):
+        raise ValueError(f"loss: batch {tuple(batch.shape)} does not match pred {tuple(pred.shape)}")
+    a = _lib.LossArgs()
+    a.B, a.C, a.L, a.mag_weight = B, Cc, L, mag_weight
+    a.pred, a.batch = _dense(pred, "pred"), _dense(batch, "batch")
+    if dpred is not None:
+        a.dpred = _dense(dpred, "dpred")
+    if losses is None:
+        losses = torch.empty(3, device=pred.device, dtype=torch.float32)
+    a.losses = _dense(losses, "losses")
+    lib = _lib.load()
+    need = lib.pg_workspace_bytes_loss(C.byref(a))
+    ws = _loss_ws.get(pred.device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, device=pred.device, dtype=torch.float32)
+        _loss_ws[pred.device] = ws
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    _lib.check(lib.pg_loss_fwd_bwd(C.byref(a), _stream()), "loss_fwd_bwd")
+    return losses
+
+
+def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    a = _lib.AdamArgs()
+    a.n = p.numel()
+    a.p, a.g, a.m, a.v = _dense(p, "p"), _dense(g, "g"), _dense(m, "m"), _dense(v, "v")
+    a.lr, a.beta1, a.beta2, a.eps, a.grad_scale, a.step = lr, beta1, beta2, eps, grad_scale, step
+    _lib.check(_lib.load().pg_adam_step(C.byref(a), _stream()), "adam_step")
+
+
+def fill(t, value):
+    _lib.check(_lib.load().pg_fill(C.c_void_p(_dense(t, "t")), t.numel(), value, _stream()), "fill")
+    return t
+
+
+def stft(y, n_fft, hop, polar=False, out=None):
+    """(n_signals, n_samples) -> (n_signals, 2, n_fft/2, 1 + n_samples // hop); preproc_mdb.py:84-97 (+ data.py:39-47)."""
+    if y.dim() == 1:
+        y = y[None]
+    n_sig, n_samp = y.shape
+    nf = 1 + n_samp // hop
+    if out is None:
+        out = torch.empty(n_sig, 2, n_fft // 2, nf, device=y.device, dtype=torch.float32)
+    a = _lib.StftArgs()
+    a.n_signals, a.n_samples, a.n_fft, a.hop, a.n_frames, a.polar = n_sig, n_samp, n_fft, hop, nf, int(polar)
+    a.y, a.out = _dense(y, "y"), _dense(out, "out")
+    _lib.check(_lib.load().pg_stft(C.byref(a), _stream()), "stft")
+    return out
+
+
+def stft_frame_index(n_samples, n_fft, hop, device="cuda"):
+    nf = 1 + n_samples // hop
+    idx = torch.empty(nf, n_fft, device=device, dtype=torch.int32)
+    _lib.check(_lib.load().pg_stft_frame_index(n_samples, n_fft, hop, nf, C.c_void_p(idx.data_ptr()), _stream()), "stft_frame_index")
+    return idx
+
+
+def polar(d, out=None):
+    """data.py:39-47: (N, 2, bins, frames) [re; im] -> [log1p|z|; angle]."""
+    if out is None:
+        out = torch.empty_like(d)
+    a = _lib.PolarArgs()
+    a.n_items, a.inner = d.shape[0], d[0, 0].numel()
+    a.inp, a.out = _dense(d, "d"), _dense(out, "out")
+    _lib.check(_lib.load().pg_polar(C.byref(a), _stream()), "polar")
+    return out
+
+
+_istft_ws = {}
+
+
+def istft(a_t, b_t, hop, mode=0, normalize=True):
+    """(n, bins, frames) x2 -> (n, hop*(frames-1)).  mode 0: (logmag, phase) per demo.py:39; mode 1: (re, im).
+    utils.py:34-42: zero DC row, librosa.istft, peak normalisation."""
+    n, bins, nf = a_t.shape
+    audio = torch.empty(n, hop * (nf - 1), device=a_t.device, dtype=torch.float32)
+    lib = _lib.load()
+    for s0 in range(0, n, 64):
+        s1 = min(n, s0 + 64)
+        a = _lib.IstftArgs()
+        a.n_signals, a.bins, a.n_frames, a.hop, a.mode, a.normalize = s1 - s0, bins, nf, hop, mode, int(normalize)
+        a.a, a.a_bs = _act3(a_t[s0:s1], "a")
+        a.b, a.b_bs = _act3(b_t[s0:s1], "b")
+        a.audio = audio[s0:s1].data_ptr()
+        need = lib.pg_workspace_bytes_istft(C.byref(a))
+        ws = _istft_ws.get(a_t.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, device=a_t.device, dtype=torch.uint8)
+            _istft_ws[a_t.device] = ws
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        _lib.check(lib.pg_istft(C.byref(a), _stream()), "istft")
+    return audio

@@ -1,0 +1,273 @@
+"""The U-Net phase generator of model.py on MI355X: parameter arena, activation plan, forward and backward.
+
+Reference wiring (model.py:27-34, 85-113), with the names used throughout this repo:
+
+    x0 --D0--> a0 --leaky,D1,BN--> h1 --leaky,D2,BN--> h2 --leaky,D3--> d3
+    d3 --relu,U3,BN--> u3 ; cat2 = [h2 | u3] --relu,U2,BN--> u2 ; cat1 = [h1 | u2] --relu,U1,BN--> u1 ;
+    cat0 = [a0 | u1] --relu,U0,BN--> out
+
+MI355X-first layout decisions:
+  * ONE flat fp32 arena for all 20 parameters (and a twin for gradients): Adam is a single streaming launch, the
+    data-parallel all-reduce works on contiguous buckets of the same arena, a checkpoint is one copy.
+  * torch.cat is never executed: each concat is one (B, 4C, L') buffer whose halves are written in place by the
+    producing BatchNorm / conv (batch-stride-aware kernels).  The in-place LeakyReLU of model.py:80 is not
+    executed either: buffers hold PRE-activation values and every consumer applies leaky / relu as it loads
+    (relu(leaky(x)) == relu(x), so the skip half needs no second copy).
+  * backward mirrors it: dgrad epilogues add the skip gradient and multiply by the activation derivative, wgrad
+    overwrites the gradient arena (zero_grad folded in).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import detgen, ops
+from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU
+
+ALIGN = 64  # floats; keeps every parameter 256-B aligned inside the arena
+
+# (key, kind, stride, pad): kind 'c' = Conv1d (Cout, Cin, k), 't' = ConvTranspose1d (Cin, Cout, k)
+LAYERS = {
+    "D0": (detgen.K_D0, "c", 2, 16), "D1": (detgen.K_D1, "c", 1, 2), "D2": (detgen.K_D2, "c", 2, 1),
+    "D3": (detgen.K_D3, "c", 2, 1), "U3": (detgen.K_U3, "t", 2, 1), "U2": (detgen.K_U2, "t", 2, 1),
+    "U1": (detgen.K_U1, "t", 1, 2), "U0": (detgen.K_U0, "t", 2, 16),
+}
+BN_OF = {"D1": detgen.BN_D1, "D2": detgen.BN_D2, "U3": detgen.BN_U3, "U2": detgen.BN_U2, "U1": detgen.BN_U1,
+         "U0": detgen.BN_U0}
+# order in which backward produces weight gradients (used for all-reduce bucketing)
+BACKWARD_ORDER = ["U0", "U1", "U2", "U3", "D3", "D2", "D1", "D0"]
+
+
+def frame_plan(L):
+    """Frame counts of every level; raises for lengths the U-Net cannot concatenate (valid: L % 8 == 0, L >= 24)."""
+    L1 = ops.conv_out_len(L, 32, 2, 16)
+    L2 = ops.conv_out_len(L1, 8, 1, 2)
+    L3 = ops.conv_out_len(L2, 8, 2, 1)
+    L4 = ops.conv_out_len(L3, 4, 2, 1)
+    ok = (L4 >= 1 and ops.convt_out_len(L4, 5, 2, 1) == L3 and ops.convt_out_len(L3, 8, 2, 1) == L2
+          and ops.convt_out_len(L2, 8, 1, 2) == L1 and ops.convt_out_len(L1, 32, 2, 16) == L)
+    if not ok:
+        raise ValueError(f"UNet: {L} frames cannot be skip-concatenated (need a multiple of 8, >= 24)")
+    return L1, L2, L3, L4
+
+
+class ParamArena:
+    """All parameters in one flat device buffer, reference state-dict names, reference parameter order."""
+
+    def __init__(self, C, device):
+        self.C = C
+        self.device = device
+        shapes = detgen.conv_shapes(C)
+        self.shapes, self.offsets = {}, {}
+        off = 0
+        for k in detgen.param_order():
+            shp = shapes[k] if k in shapes else (2 * C,)
+            self.shapes[k], self.offsets[k] = shp, off
+            off += (int(np.prod(shp)) + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=device, dtype=torch.float32)
+        self.buffers = {}
+        for k in detgen.BN_KEYS:
+            self.buffers[k + ".running_mean"] = torch.zeros(2 * C, device=device)
+            self.buffers[k + ".running_var"] = torch.ones(2 * C, device=device)
+            self.buffers[k + ".num_batches_tracked"] = torch.zeros((), device=device, dtype=torch.long)
+
+    def view(self, k, of=None):
+        base = self.flat if of is None else of
+        n = int(np.prod(self.shapes[k]))
+        return base[self.offsets[k]: self.offsets[k] + n].view(self.shapes[k])
+
+    def p(self, k):
+        return self.view(k)
+
+    def g(self, k):
+        return self.view(k, self.grad)
+
+    def span(self, keys):
+        """(start, end) float offsets of the arena range covering ``keys`` (must be adjacent in the arena)."""
+        s = min(self.offsets[k] for k in keys)
+        e = max(self.offsets[k] + (int(np.prod(self.shapes[k])) + ALIGN - 1) // ALIGN * ALIGN for k in keys)
+        return s, e
+
+    def init_default(self, seed=None):
+        """torch's default init (model.py builds stock nn.Conv1d / nn.ConvTranspose1d / BatchNorm; weights_init
+        at model.py:12-20 is never called): conv weights U(+-1/sqrt(fan_in)), gamma 1, beta 0."""
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(torch.initial_seed() if seed is None else seed)
+        for k, shp in self.shapes.items():
+            v = self.view(k)
+            if len(shp) == 3:
+                b = 1.0 / math.sqrt(detgen.fan_in(k, shp))
+                v.uniform_(-b, b, generator=gen)
+            elif k.endswith(".weight"):
+                v.fill_(1.0)
+            else:
+                v.zero_()
+
+    def load_numpy(self, params):
+        for k in self.shapes:
+            self.view(k).copy_(torch.from_numpy(np.ascontiguousarray(params[k])))
+        for k in self.buffers:
+            if k in params:
+                self.buffers[k].copy_(torch.as_tensor(np.asarray(params[k])))
+
+
+class UNetEngine:
+    """Forward / backward of the whole network through libphasegen, with a per-(B, L) activation plan."""
+
+    def __init__(self, C, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("phasegen.UNetEngine needs an MI355X (no CPU fallback exists for the hot path)")
+        self.C = C
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.arena = ParamArena(C, self.device)
+        self.plans = {}
+        self.bn_save = {k: (torch.empty(2 * C, device=self.device), torch.empty(2 * C, device=self.device))
+                        for k in BN_OF}
+        self.cur = None
+
+    # -- activation plan ---------------------------------------------------------------------------------------
+    def plan(self, B, L):
+        key = (B, L)
+        if key not in self.plans:
+            C = self.C
+            L1, L2, L3, L4 = frame_plan(L)
+            dev = self.device
+
+            def z(*s):
+                return torch.empty(*s, device=dev, dtype=torch.float32)
+            f = dict(cat0=z(B, 4 * C, L1), cat1=z(B, 4 * C, L2), cat2=z(B, 4 * C, L3), d3=z(B, 4 * C, L4),
+                     c1=z(B, 2 * C, L2), c2=z(B, 2 * C, L3), r3=z(B, 2 * C, L3), r2=z(B, 2 * C, L2),
+                     r1=z(B, 2 * C, L1), r0=z(B, 2 * C, L), out=z(B, 2 * C, L))
+            self.plans[key] = dict(fwd=f, bwd=None, L=(L, L1, L2, L3, L4))
+        return self.plans[key]
+
+    def _bwd_bufs(self, plan, B):
+        if plan["bwd"] is None:
+            C = self.C
+            L, L1, L2, L3, L4 = plan["L"]
+            dev = self.device
+
+            def z(*s):
+                return torch.empty(*s, device=dev, dtype=torch.float32)
+            plan["bwd"] = dict(g_r0=z(B, 2 * C, L), g_cat0=z(B, 4 * C, L1), g_r1=z(B, 2 * C, L1),
+                               g_cat1=z(B, 4 * C, L2), g_r2=z(B, 2 * C, L2), g_cat2=z(B, 4 * C, L3),
+                               g_r3=z(B, 2 * C, L3), g_d3=z(B, 4 * C, L4), g_c2=z(B, 2 * C, L3), g_c1=z(B, 2 * C, L2))
+        return plan["bwd"]
+
+    # -- helpers -----------------------------------------------------------------------------------------------
+    def _conv(self, name, x, y, act):
+        key, kind, s, p = LAYERS[name]
+        ops.conv_fwd(x, self.arena.p(key), y, s, p, x_act=act, transposed=(kind == "t"))
+
+    def _bn(self, name, x, y, update_stats):
+        key = BN_OF[name]
+        a = self.arena
+        sm, si = self.bn_save[name]
+        rm = a.buffers[key + ".running_mean"] if update_stats else None
+        rv = a.buffers[key + ".running_var"] if update_stats else None
+        ops.bn_fwd(x, y, a.p(key + ".weight"), a.p(key + ".bias"), sm, si, rm, rv)
+        if update_stats:
+            a.buffers[key + ".num_batches_tracked"] += 1
+
+    # -- forward -----------------------------------------------------------------------------------------------
+    def forward(self, x, update_stats=True):
+        """x: (B, C, L) fp32 device tensor -> (B, 2C, L).  BatchNorm is ALWAYS in training mode, as in the
+        reference (no .eval() anywhere; demo.py:36 runs batch-of-1 statistics)."""
+        if x.dim() != 3 or x.shape[1] != self.C:
+            raise ValueError(f"UNet: expected input (B, {self.C}, L), got {tuple(x.shape)}")
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise ValueError("UNet: input must be a float32 device tensor")
+        x = x.contiguous()
+        B, C, L = x.shape
+        plan = self.plan(B, L)
+        f = plan["fwd"]
+        h = 2 * C
+        self._conv("D0", x, f["cat0"][:, :h], ACT_NONE)
+        self._conv("D1", f["cat0"][:, :h], f["c1"], ACT_LEAKY)
+        self._bn("D1", f["c1"], f["cat1"][:, :h], update_stats)
+        self._conv("D2", f["cat1"][:, :h], f["c2"], ACT_LEAKY)
+        self._bn("D2", f["c2"], f["cat2"][:, :h], update_stats)
+        self._conv("D3", f["cat2"][:, :h], f["d3"], ACT_LEAKY)
+        self._conv("U3", f["d3"], f["r3"], ACT_RELU)
+        self._bn("U3", f["r3"], f["cat2"][:, h:], update_stats)
+        self._conv("U2", f["cat2"], f["r2"], ACT_RELU)
+        self._bn("U2", f["r2"], f["cat1"][:, h:], update_stats)
+        self._conv("U1", f["cat1"], f["r1"], ACT_RELU)
+        self._bn("U1", f["r1"], f["cat0"][:, h:], update_stats)
+        self._conv("U0", f["cat0"], f["r0"], ACT_RELU)
+        self._bn("U0", f["r0"], f["out"], update_stats)
+        self.cur = (plan, x)
+        return f["out"]
+
+    # -- backward ----------------------------------------------------------------------------------------------
+    def backward(self, g_out, on_grads_ready=None):
+        """Gradients of all 20 parameters into the gradient arena (overwritten).  ``on_grads_ready(layer)`` is
+        called right after the kernels that complete a layer's gradients (conv weight + its BatchNorm's gamma/beta)
+        have been enqueued -- the data-parallel wrapper launches that bucket's all-reduce from it."""
+        if self.cur is None:
+            raise RuntimeError("UNet.backward called before forward")
+        plan, x0 = self.cur
+        f = plan["fwd"]
+        B = x0.shape[0]
+        g = self._bwd_bufs(plan, B)
+        a = self.arena
+        h = 2 * self.C
+        g_out = g_out.contiguous()
+
+        def bn_bwd(name, raw, dy, dx):
+            key = BN_OF[name]
+            sm, si = self.bn_save[name]
+            ops.bn_bwd(raw, dy, dx, a.p(key + ".weight"), sm, si, a.g(key + ".weight"), a.g(key + ".bias"))
+
+        def wgrad(name, x, dy, act):
+            key, kind, s, p = LAYERS[name]
+            ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"))
+
+        def dgrad(name, dy, dx, **kw):
+            key, kind, s, p = LAYERS[name]
+            ops.conv_dgrad(dy, a.p(key), dx, s, p, transposed=(kind == "t"), **kw)
+
+        def ready(name):
+            if on_grads_ready is not None:
+                on_grads_ready(name)
+
+        # up path, outermost first
+        for name, cat, raw, gin, g_raw, g_cat in (("U0", "cat0", "r0", g_out, "g_r0", "g_cat0"),
+                                                  ("U1", "cat1", "r1", g["g_cat0"][:, h:], "g_r1", "g_cat1"),
+                                                  ("U2", "cat2", "r2", g["g_cat1"][:, h:], "g_r2", "g_cat2"),
+                                                  ("U3", "d3", "r3", g["g_cat2"][:, h:], "g_r3", "g_d3")):
+            bn_bwd(name, f[raw], gin, g[g_raw])
+            wgrad(name, f[cat], g[g_raw], ACT_RELU)
+            ready(name)
+            dgrad(name, g[g_raw], g[g_cat], ref=f[cat], mask=ACT_RELU)
+        # down path, innermost first; each dgrad adds the skip gradient and applies leaky'
+        wgrad("D3", f["cat2"][:, :h], g["g_d3"], ACT_LEAKY)
+        ready("D3")
+        dgrad("D3", g["g_d3"], g["g_cat2"][:, :h], add=g["g_cat2"][:, :h], ref=f["cat2"][:, :h], mask=ACT_LEAKY)
+        bn_bwd("D2", f["c2"], g["g_cat2"][:, :h], g["g_c2"])
+        wgrad("D2", f["cat1"][:, :h], g["g_c2"], ACT_LEAKY)
+        ready("D2")
+        dgrad("D2", g["g_c2"], g["g_cat1"][:, :h], add=g["g_cat1"][:, :h], ref=f["cat1"][:, :h], mask=ACT_LEAKY)
+        bn_bwd("D1", f["c1"], g["g_cat1"][:, :h], g["g_c1"])
+        wgrad("D1", f["cat0"][:, :h], g["g_c1"], ACT_LEAKY)
+        ready("D1")
+        dgrad("D1", g["g_c1"], g["g_cat0"][:, :h], add=g["g_cat0"][:, :h], ref=f["cat0"][:, :h], mask=ACT_LEAKY)
+        wgrad("D0", x0, g["g_cat0"][:, :h], ACT_NONE)      # network input needs no dgrad
+        ready("D0")
+
+    def layer_param_keys(self, name):
+        keys = [LAYERS[name][0]]
+        if name in BN_OF:
+            keys += [BN_OF[name] + ".weight", BN_OF[name] + ".bias"]
+        return keys
+
+    def intermediates(self):
+        """Forward tensors by oracle name (test hook)."""
+        plan, _ = self.cur
+        f = plan["fwd"]
+        h = 2 * self.C
+        return dict(a0=f["cat0"][:, :h], c1=f["c1"], h1=f["cat1"][:, :h], c2=f["c2"], h2=f["cat2"][:, :h], d3=f["d3"],
+                    r3=f["r3"], u3=f["cat2"][:, h:], r2=f["r2"], u2=f["cat1"][:, h:], r1=f["r1"], u1=f["cat0"][:, h:],
+                    r0=f["r0"], out=f["out"])
