@@ -17,6 +17,41 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """HIP-event timing of labelled launches on the stream they are launched on (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.records = {}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.records.items()}
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+class timed:
+    def __init__(self, label):
+        self.label = label
+
+    def __enter__(self):
+        if _timer is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _timer.records.setdefault(self.label, []).append((self.a, b))
+
+
 def _act3(t, name):
     """(ptr, batch_stride) of a (B, C, L) fp32 device view with L-contiguous channels."""
     if t is None:

@@ -159,7 +159,8 @@ class UNetEngine:
     # -- helpers -----------------------------------------------------------------------------------------------
     def _conv(self, name, x, y, act):
         key, kind, s, p = LAYERS[name]
-        ops.conv_fwd(x, self.arena.p(key), y, s, p, x_act=act, transposed=(kind == "t"))
+        with ops.timed(name + ".fwd"):
+            ops.conv_fwd(x, self.arena.p(key), y, s, p, x_act=act, transposed=(kind == "t"))
 
     def _bn(self, name, x, y, update_stats):
         key = BN_OF[name]
@@ -179,8 +180,7 @@ class UNetEngine:
             raise ValueError(f"UNet: expected input (B, {self.C}, L), got {tuple(x.shape)}")
         if not x.is_cuda or x.dtype != torch.float32:
             raise ValueError("UNet: input must be a float32 device tensor")
-        x = x.contiguous()
-        B, C, L = x.shape
+        B, C, L = x.shape           # batch-strided views (e.g. batch[:, 0] of a (B,2,C,L) batch) are read in place
         plan = self.plan(B, L)
         f = plan["fwd"]
         h = 2 * C
@@ -223,11 +223,13 @@ class UNetEngine:
 
         def wgrad(name, x, dy, act):
             key, kind, s, p = LAYERS[name]
-            ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"))
+            with ops.timed(name + ".wgrad"):
+                ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"))
 
         def dgrad(name, dy, dx, **kw):
             key, kind, s, p = LAYERS[name]
-            ops.conv_dgrad(dy, a.p(key), dx, s, p, transposed=(kind == "t"), **kw)
+            with ops.timed(name + ".dgrad"):
+                ops.conv_dgrad(dy, a.p(key), dx, s, p, transposed=(kind == "t"), **kw)
 
         def ready(name):
             if on_grads_ready is not None:
