@@ -39,22 +39,32 @@ struct IgemmParams {
     float* y; long y_bs;             // F,T: output activations; G: dW
     const float* add; long add_bs;   // optional epilogue addend (same shape as y)
     const float* ref; long ref_bs;   // optional epilogue mask source (same shape as y)
+    unsigned x_bytes, w_bytes, pt_bytes;   // extents for the buffer descriptors (hardware bounds check)
     int B, Q, M, Lx, Ly, k, s, p;    // Q: channels of x; M: output channels (F,T) / channels of P (G)
     int act_x, act_p, mask_mode;
     int U, u_off;                    // T: positions per phase, first u
-    int LP;                          // G: frames of P
+    int LP; float inv_LP;            // G: frames of P and 1/LP
+    int a_vec;                       // F: weight rows may be read as aligned float4
     int tilesM, tilesN;
 };
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == PG_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
-    if (act == PG_ACT_RELU) return v > 0.f ? v : 0.f;
-    return v;
+// Activations are applied branch-free as max(v,0) + slope*min(v,0): slope 1 = identity, 0.2 = LeakyReLU(0.2)
+// (model.py:80), 0 = ReLU (model.py:82).  A runtime switch here would make hipcc branch around every gathered
+// element and wait vmcnt(0) for each load in turn.
+__host__ __device__ __forceinline__ float act_slope(int act) {
+    return act == PG_ACT_LEAKY02 ? 0.2f : (act == PG_ACT_RELU ? 0.0f : 1.0f);
 }
-__device__ __forceinline__ float act_grad(float v, int act) {
-    if (act == PG_ACT_LEAKY02) return v > 0.f ? 1.f : 0.2f;
-    if (act == PG_ACT_RELU) return v > 0.f ? 1.f : 0.f;
-    return 1.f;
+__device__ __forceinline__ float act_apply(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+
+// Operand gathers go through buffer descriptors: a lane whose element is padding / out of the tile / past K gets
+// the offset OOB and the hardware returns 0.0 -- no exec-masked branch around the load, no 64-bit address math.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int OOB = 0x7ffffff0;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, int elem_off, bool ok) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, ok ? elem_off * 4 : OOB, 0, 0));
 }
 
 // XCD-aware, bijective remap of the linear workgroup id: hardware deals consecutive ids round-robin over the
@@ -94,21 +104,36 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const flo
 // Register-staged tiles: each thread carries 2 x float4 of A and 2 x float4 of B per slab.
 struct Stage { f32x4 a[2], b[2]; };
 
-__device__ __forceinline__ void stage_store(float* As, float* Bs, const Stage& st, int tid) {
+__device__ __forceinline__ void stage_store(float* As, float* Bs, const Stage& st, int tid, float slopeA, float slopeB) {
     // A: thread -> (row = tid>>2 (+64), kgroup = tid&3);  B: thread -> (row = tid&127, kgroup = tid>>7 (+2))
+    // Activation happens HERE (after the MFMA block in program order), never at the load, so the gathers of the
+    // next slab stay in flight underneath the matrix work.
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        *reinterpret_cast<f32x4*>(As + ((tid >> 2) + 64 * e) * LDT + (tid & 3) * 4) = st.a[e];
-        *reinterpret_cast<f32x4*>(Bs + (tid & 127) * LDT + ((tid >> 7) + 2 * e) * 4) = st.b[e];
+        f32x4 a = st.a[e], b = st.b[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = act_apply(a[i], slopeA); b[i] = act_apply(b[i], slopeB); }
+        *reinterpret_cast<f32x4*>(As + ((tid >> 2) + 64 * e) * LDT + (tid & 3) * 4) = a;
+        *reinterpret_cast<f32x4*>(Bs + (tid & 127) * LDT + ((tid >> 7) + 2 * e) * 4) = b;
     }
 }
 
-// Epilogue value: optional addend, optional activation-derivative mask.
-__device__ __forceinline__ float epi(const IgemmParams& p, float v, long idx_add, long idx_ref) {
-    if (p.add) v += p.add[idx_add];
-    if (p.mask_mode) v *= act_grad(p.ref[idx_ref], p.mask_mode);
-    return v;
-}
+// Fused dgrad epilogue: v = (acc + add) * act'(ref).  A missing addend / mask source is an EMPTY descriptor (every
+// load returns 0) and slope 1, so the same branch-free code serves all combinations.
+struct Epi {
+    rsrc_t radd, rref; float slope; bool fused;
+    __device__ __forceinline__ Epi(const IgemmParams& p, unsigned ybytes)
+        : radd(make_rsrc(p.add, p.add ? ybytes_of(p.add_bs, p, ybytes) : 0u)),
+          rref(make_rsrc(p.ref, (p.ref && p.mask_mode) ? ybytes_of(p.ref_bs, p, ybytes) : 0u)),
+          slope((p.ref && p.mask_mode) ? act_slope(p.mask_mode) : 1.0f), fused(p.add || (p.ref && p.mask_mode)) {}
+    static __device__ __forceinline__ unsigned ybytes_of(long bs, const IgemmParams& p, unsigned ybytes) {
+        return (unsigned)(((long)(p.B - 1) * bs) * 4) + ybytes;
+    }
+    __device__ __forceinline__ float operator()(float v, int off_add, int off_ref) const {
+        v += bload(radd, off_add, true);
+        return v * (bload(rref, off_ref, true) > 0.f ? 1.0f : slope);
+    }
+};
 
 #define PG_MAINLOOP(LOAD_A, LOAD_B)                                                     \
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE];                        \
@@ -118,14 +143,14 @@ __device__ __forceinline__ float epi(const IgemmParams& p, float v, long idx_add
     Stage st;                                                                           \
     const int nslab = (Ktot + BK - 1) / BK;                                             \
     { const int k0 = 0; LOAD_A; LOAD_B; }                                               \
-    stage_store(lds, lds + TILE, st, tid);                                              \
+    stage_store(lds, lds + TILE, st, tid, slopeA, slopeB);                                              \
     __syncthreads();                                                                    \
     for (int sl = 0; sl < nslab; ++sl) {                                                \
         const int cur = sl & 1;                                                         \
-        const bool more = sl + 1 < nslab;                                               \
-        if (more) { const int k0 = (sl + 1) * BK; LOAD_A; LOAD_B; }                     \
+        const int k0 = (sl + 1) * BK;      /* past-the-end slab loads only zeros */     \
+        LOAD_A; LOAD_B;                                                                 \
         mma_slab(lds + cur * 2 * TILE, lds + cur * 2 * TILE + TILE, lane, wm, wn, acc); \
-        if (more) stage_store(lds + (cur ^ 1) * 2 * TILE, lds + (cur ^ 1) * 2 * TILE + TILE, st, tid); \
+        stage_store(lds + (cur ^ 1) * 2 * TILE, lds + (cur ^ 1) * 2 * TILE + TILE, st, tid, slopeA, slopeB); \
         __syncthreads();                                                                \
     }
 
@@ -139,57 +164,66 @@ __global__ __launch_bounds__(NT) void conv_f_kernel(const IgemmParams p) {
     const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
     const int kw = KW ? KW : p.k, s = S ? S : p.s;
     const int Ktot = p.Q * kw, Ntot = p.B * p.Ly;
-    const bool avec = (Ktot & 3) == 0;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
 
-    // B-operand (im2col) thread constants: one output position n per thread.
+    // A operand (weights, K-contiguous rows): thread -> rows (tid>>2) + 64e, k-group tid&3
+    int arow[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int m = m0 + (tid >> 2) + 64 * e;
+        arow[e] = m < p.M ? m * Ktot + (tid & 3) * 4 : -1;
+    }
+    // B operand (im2col): one output position n per thread
     const int nB = n0 + (tid & 127);
     const bool nvalid = nB < Ntot;
     const int bB = nvalid ? nB / p.Ly : 0, tB = nvalid ? nB - bB * p.Ly : 0;
-    const float* xb = p.x + (long)bB * p.x_bs + (s * tB - p.p);
-    const int jlo = p.p - s * tB, jhi = p.Lx + p.p - s * tB;   // taps with 0 <= s*t+j-p < Lx
-    const int act = p.act_x;
-    const float* __restrict__ w = p.w;
+    const int xoff = bB * (int)p.x_bs + s * tB - p.p;          // element offset of tap j = 0, channel 0
+    const int jlo = p.p - s * tB;                              // valid taps: 0 <= j - jlo < Lx
+    const unsigned jspan = nvalid ? (unsigned)p.Lx : 0u;
+    const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
 
 #define F_LOAD_A                                                                                   \
     _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-        const int m = m0 + (tid >> 2) + 64 * e, kk = k0 + (tid & 3) * 4;                           \
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                            \
-        if (m < p.M) {                                                                             \
-            const float* src = w + (long)m * Ktot + kk;                                            \
-            if (avec) { if (kk < Ktot) v = *reinterpret_cast<const f32x4*>(src); }                 \
-            else { _Pragma("unroll") for (int i = 0; i < 4; ++i) if (kk + i < Ktot) v[i] = src[i]; } \
+        const int kk = k0 + (tid & 3) * 4;                                                         \
+        if (p.a_vec) {                                                                             \
+            const bool ok = arow[e] >= 0 && kk < Ktot;                                             \
+            st.a[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? (arow[e] + k0) * 4 : OOB, 0, 0)); \
+        } else {                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
+                st.a[e][i] = bload(rw, arow[e] + k0 + i, arow[e] >= 0 && kk + i < Ktot);           \
         }                                                                                          \
-        st.a[e] = v;                                                                               \
     }
 #define F_LOAD_B                                                                                   \
     _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
         const int kk0 = k0 + ((tid >> 7) + 2 * e) * 4;                                             \
-        f32x4 v;                                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
             const int kk = kk0 + i, q = kk / kw, j = kk - q * kw;                                  \
-            const bool ok = nvalid && kk < Ktot && j >= jlo && j < jhi;                            \
-            v[i] = ok ? act_apply(xb[(long)q * p.Lx + j], act) : 0.f;                              \
+            const bool ok = kk < Ktot && (unsigned)(j - jlo) < jspan;                              \
+            st.b[e][i] = bload(rx, xoff + q * p.Lx + j, ok);                       \
         }                                                                                          \
-        st.b[e] = v;                                                                               \
     }
     PG_MAINLOOP(F_LOAD_A, F_LOAD_B)
 #undef F_LOAD_A
 #undef F_LOAD_B
 
     // epilogue: acc reg r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+    const Epi ep(p, (unsigned)((long)p.M * p.Ly * 4));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
         if (n >= Ntot) continue;
         const int b = n / p.Ly, t = n - b * p.Ly;
+        float* yb = p.y + (long)b * p.y_bs;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
-                    const long off = (long)m * p.Ly + t;
-                    p.y[(long)b * p.y_bs + off] = epi(p, acc.c[i][j][r], (long)b * p.add_bs + off, (long)b * p.ref_bs + off);
+                    const int off = m * p.Ly + t;
+                    float v = acc.c[i][j][r];
+                    if (ep.fused) v = ep(v, b * (int)p.add_bs + off, b * (int)p.ref_bs + off);
+                    yb[off] = v;
                 }
             }
     }
@@ -206,47 +240,54 @@ __global__ __launch_bounds__(NT) void conv_t_kernel(const IgemmParams p) {
     const int kw = KW ? KW : p.k, s = S ? S : p.s;
     const int KJ = (kw + s - 1) / s;
     const int Ktot = p.Q * KJ, Ntot = p.B * p.U, Mrows = p.M * s;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    const int wq = p.M * kw;                  // weight stride between input channels q
 
+    // A operand: W[q][o][s*jj + phi]; thread -> rows m' = (tid>>2) + 64e (o = m'/s, phi = m'%s), k-group tid&3
+    int arow[2], aphi[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int mr = m0 + (tid >> 2) + 64 * e, o = mr / s;
+        aphi[e] = mr - o * s;
+        arow[e] = mr < Mrows ? o * kw + aphi[e] : -1;
+    }
+    // B operand: X[b][q][u - jj]; one (b, u) per thread
     const int nB = n0 + (tid & 127);
     const bool nvalid = nB < Ntot;
     const int bB = nvalid ? nB / p.U : 0, uB = (nvalid ? nB - bB * p.U : 0) + p.u_off;
-    const float* xb = p.x + (long)bB * p.x_bs + uB;
-    const int act = p.act_x;
-    const float* __restrict__ w = p.w;
-    const long wq = (long)p.M * kw;           // weight stride between input channels q
+    const int xoff = bB * (int)p.x_bs + uB;
+    const unsigned xspan = nvalid ? (unsigned)p.Lx : 0u;
+    const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
 
 #define T_LOAD_A                                                                                   \
     _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-        const int mr = m0 + (tid >> 2) + 64 * e, o = mr / s, phi = mr - o * s;                     \
         const int kk0 = k0 + (tid & 3) * 4;                                                        \
-        f32x4 v;                                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            const int kk = kk0 + i, q = kk / KJ, jj = kk - q * KJ, j = s * jj + phi;               \
-            const bool ok = mr < Mrows && kk < Ktot && j < kw;                                     \
-            v[i] = ok ? w[q * wq + (long)o * kw + j] : 0.f;                                        \
+            const int kk = kk0 + i, q = kk / KJ, jj = kk - q * KJ;                                 \
+            const bool ok = arow[e] >= 0 && kk < Ktot && s * jj + aphi[e] < kw;                    \
+            st.a[e][i] = bload(rw, q * wq + arow[e] + s * jj, ok);                                 \
         }                                                                                          \
-        st.a[e] = v;                                                                               \
     }
 #define T_LOAD_B                                                                                   \
     _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
         const int kk0 = k0 + ((tid >> 7) + 2 * e) * 4;                                             \
-        f32x4 v;                                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            const int kk = kk0 + i, q = kk / KJ, jj = kk - q * KJ, pos = uB - jj;                  \
-            const bool ok = nvalid && kk < Ktot && pos >= 0 && pos < p.Lx;                         \
-            v[i] = ok ? act_apply(xb[(long)q * p.Lx - jj], act) : 0.f;                             \
+            const int kk = kk0 + i, q = kk / KJ, jj = kk - q * KJ;                                 \
+            const bool ok = kk < Ktot && (unsigned)(uB - jj) < xspan;                              \
+            st.b[e][i] = bload(rx, xoff + q * p.Lx - jj, ok);                      \
         }                                                                                          \
-        st.b[e] = v;                                                                               \
     }
     PG_MAINLOOP(T_LOAD_A, T_LOAD_B)
 #undef T_LOAD_A
 #undef T_LOAD_B
 
+    const Epi ep(p, (unsigned)((long)p.M * p.Ly * 4));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
         if (n >= Ntot) continue;
         const int b = n / p.U, u = n - b * p.U + p.u_off;
+        float* yb = p.y + (long)b * p.y_bs;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -254,8 +295,10 @@ __global__ __launch_bounds__(NT) void conv_t_kernel(const IgemmParams p) {
                 const int mr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int o = mr / s, phi = mr - o * s, tau = s * u + phi - p.p;
                 if (mr < Mrows && tau >= 0 && tau < p.Ly) {
-                    const long off = (long)o * p.Ly + tau;
-                    p.y[(long)b * p.y_bs + off] = epi(p, acc.c[i][j][r], (long)b * p.add_bs + off, (long)b * p.ref_bs + off);
+                    const int off = o * p.Ly + tau;
+                    float v = acc.c[i][j][r];
+                    if (ep.fused) v = ep(v, b * (int)p.add_bs + off, b * (int)p.ref_bs + off);
+                    yb[off] = v;
                 }
             }
     }
@@ -264,6 +307,14 @@ __global__ __launch_bounds__(NT) void conv_t_kernel(const IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------
 // G kernel.  dW[m][(q,j)] = sum over kk = (b,i) of actP(P[b,m,i]) * actQ(Q[b,q,s*i+j-p]);  Q tensor is p.x.
 // ------------------------------------------------------------------------------------------------------------
+// n / d for 0 <= n < 2^24 via the float reciprocal, exact after one correction step (branch-free selects).
+__device__ __forceinline__ void divmod24(int n, int d, float inv, int& q, int& r) {
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { r += d; --q; }
+    if (r >= d) { r -= d; ++q; }
+}
+
 template <int KW, int S>
 __global__ __launch_bounds__(NT) void conv_g_kernel(const IgemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -271,49 +322,48 @@ __global__ __launch_bounds__(NT) void conv_g_kernel(const IgemmParams p) {
     const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
     const int kw = KW ? KW : p.k, s = S ? S : p.s;
     const int Ktot = p.B * p.LP, Ntot = p.Q * kw;
+    const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
 
-    // B operand: one (q,j) per thread
+    // A operand: P[b][m][i]; thread -> rows (tid>>2) + 64e, k-group tid&3
+    int arow[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int m = m0 + (tid >> 2) + 64 * e;
+        arow[e] = m < p.M ? m * p.LP : -1;
+    }
+    // B operand: Q[b][q][s*i + j - p]; one (q, j) per thread
     const int nB = n0 + (tid & 127);
     const bool nvalid = nB < Ntot;
     const int qB = nvalid ? nB / kw : 0, jB = nvalid ? nB - qB * kw : 0;
-    const float* xq = p.x + (long)qB * p.Lx + (jB - p.p);
-    const int actq = p.act_x, actp = p.act_p;
-    const float* __restrict__ pt = p.pt;
-    // running (b, i) decode of this thread's first kk of the slab, for A (kgroup tid&3) and B (kgroups tid>>7, +2)
-    int kA = (tid & 3) * 4, bA = kA / p.LP, iA = kA - bA * p.LP;
-    int kB0 = (tid >> 7) * 4, bB0 = kB0 / p.LP, iB0 = kB0 - bB0 * p.LP;
-    int kB1 = kB0 + 8, bB1 = kB1 / p.LP, iB1 = kB1 - bB1 * p.LP;
-    int kprev = 0;
+    const int xoff = qB * p.Lx + jB - p.p;
+    const unsigned xspan = nvalid ? (unsigned)p.Lx : 0u;
+    const float slopeA = act_slope(p.act_p), slopeB = act_slope(p.act_x);
+    const int pbs = (int)p.pt_bs, xbs = (int)p.x_bs;
 
-#define G_ADVANCE(bb, ii, d) { ii += (d); while (ii >= p.LP) { ii -= p.LP; ++bb; } }
 #define G_LOAD_A                                                                                   \
-    { const int d = k0 - kprev; kprev = k0;                                                        \
-      G_ADVANCE(bA, iA, d) G_ADVANCE(bB0, iB0, d) G_ADVANCE(bB1, iB1, d) }                         \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-        const int m = m0 + (tid >> 2) + 64 * e;                                                    \
-        int bb = bA, ii = iA; f32x4 v;                                                             \
+    {                                                                                              \
+        int bb, ii;                                                                                \
+        divmod24(k0 + (tid & 3) * 4, p.LP, p.inv_LP, bb, ii);                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            const bool ok = m < p.M && bb < p.B;                                                   \
-            v[i] = ok ? act_apply(pt[(long)bb * p.pt_bs + (long)m * p.LP + ii], actp) : 0.f;       \
-            if (++ii == p.LP) { ii = 0; ++bb; }                                                    \
+            const bool okb = bb < p.B;                                                             \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e)                                          \
+                st.a[e][i] = bload(rp, bb * pbs + arow[e] + ii, okb && arow[e] >= 0); \
+            ++ii; if (ii == p.LP) { ii = 0; ++bb; }                                                \
         }                                                                                          \
-        st.a[e] = v;                                                                               \
     }
 #define G_LOAD_B                                                                                   \
     _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-        int bb = e ? bB1 : bB0, ii = e ? iB1 : iB0; f32x4 v;                                       \
+        int bb, ii;                                                                                \
+        divmod24(k0 + ((tid >> 7) + 2 * e) * 4, p.LP, p.inv_LP, bb, ii);                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            const int pos = s * ii + jB - p.p;                                                     \
-            const bool ok = nvalid && bb < p.B && pos >= 0 && pos < p.Lx;                          \
-            v[i] = ok ? act_apply(xq[(long)bb * p.x_bs + s * ii], actq) : 0.f;                     \
-            if (++ii == p.LP) { ii = 0; ++bb; }                                                    \
+            const bool ok = bb < p.B && (unsigned)(s * ii + jB - p.p) < xspan;                     \
+            st.b[e][i] = bload(rx, bb * xbs + xoff + s * ii, ok);                 \
+            ++ii; if (ii == p.LP) { ii = 0; ++bb; }                                                \
         }                                                                                          \
-        st.b[e] = v;                                                                               \
     }
     PG_MAINLOOP(G_LOAD_A, G_LOAD_B)
 #undef G_LOAD_A
 #undef G_LOAD_B
-#undef G_ADVANCE
 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -360,6 +410,12 @@ int launch(Kind kind, IgemmParams& p, long rows, long cols, hipStream_t st) {
     return PG_OK;
 }
 
+// bytes spanned by a (B, C, L) view with batch stride bs; 0 if it does not fit 31-bit buffer offsets
+unsigned extent_bytes(long B, long bs, long C, long L) {
+    const long e = ((B - 1) * bs + C * L) * 4;
+    return (e > 0 && e < 0x7ffffff0L) ? (unsigned)e : 0u;
+}
+
 int check_geom(const pg_conv_args* a, bool transposed) {
     if (!a) return pg_fail(PG_ERR_NULL, "conv: null args");
     if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->Lin <= 0 || a->Lout <= 0 || a->k <= 0 || a->stride <= 0 || a->pad < 0)
@@ -367,8 +423,22 @@ int check_geom(const pg_conv_args* a, bool transposed) {
     const long lo = transposed ? (long)(a->Lin - 1) * a->stride - 2L * a->pad + a->k
                                : ((long)a->Lin + 2L * a->pad - a->k) / a->stride + 1;
     if (lo != a->Lout) return pg_fail(PG_ERR_SHAPE, "conv: Lout inconsistent with Lin/k/stride/pad");
-    if ((long)a->B * (long)(a->Cin > a->Cout ? a->Cin : a->Cout) * (long)(a->Lin > a->Lout ? a->Lin : a->Lout) > 0x7fffffffL)
-        return pg_fail(PG_ERR_SHAPE, "conv: tensor exceeds 2^31 elements");
+    if ((long)a->Cin * a->Cout * a->k * 4 >= 0x7ffffff0L) return pg_fail(PG_ERR_SHAPE, "conv: weight tensor exceeds 2 GiB");
+    return PG_OK;
+}
+
+// fills the descriptor extents of the tensors a kernel gathers from; fails if one exceeds 31-bit byte offsets
+int set_extents(IgemmParams& p, long xC, long xL, long ptC, long ptL) {
+    p.x_bytes = extent_bytes(p.B, p.x_bs, xC, xL);
+    if (!p.x_bytes) return pg_fail(PG_ERR_SHAPE, "conv: activation tensor exceeds 2 GiB (31-bit buffer offsets)");
+    if (p.w) p.w_bytes = (unsigned)((long)p.M * p.Q * p.k * 4);
+    if (p.pt) {
+        p.pt_bytes = extent_bytes(p.B, p.pt_bs, ptC, ptL);
+        if (!p.pt_bytes) return pg_fail(PG_ERR_SHAPE, "conv: activation tensor exceeds 2 GiB (31-bit buffer offsets)");
+        if ((long)p.B * p.LP >= (1L << 24) - 64) return pg_fail(PG_ERR_UNSUPPORTED, "wgrad: B*L must stay below 2^24");
+        p.inv_LP = 1.0f / (float)p.LP;
+    }
+    p.a_vec = p.w && (((long)p.Q * p.k) & 3) == 0 && ((uintptr_t)p.w & 15) == 0;
     return PG_OK;
 }
 
@@ -382,6 +452,7 @@ extern "C" int pg_conv1d_fwd(const pg_conv_args* a, void* stream) {
     p.x = a->x; p.x_bs = a->x_bs; p.w = a->w; p.y = a->y; p.y_bs = a->y_bs;
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.Ly = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
     p.act_x = a->x_act;
+    if (int e = set_extents(p, p.Q, p.Lx, 0, 0)) return e;
     return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (hipStream_t)stream);
 }
 
@@ -394,6 +465,7 @@ extern "C" int pg_convt1d_dgrad(const pg_conv_args* a, void* stream) {
     p.add = a->dx_add; p.add_bs = a->dx_add_bs; p.ref = a->dx_ref; p.ref_bs = a->dx_ref_bs;
     p.mask_mode = a->dx_ref ? a->dx_mask : 0;
     p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.Ly = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    if (int e = set_extents(p, p.Q, p.Lx, 0, 0)) return e;
     return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (hipStream_t)stream);
 }
 
@@ -403,6 +475,7 @@ static int launch_t(IgemmParams& p, hipStream_t st) {
     const int u_max = (p.Ly - 1 + p.p) / p.s;
     p.U = u_max - p.u_off + 1;
     if (p.U <= 0) return pg_fail(PG_ERR_SHAPE, "convT: empty output");
+    if (int e = set_extents(p, p.Q, p.Lx, 0, 0)) return e;
     return launch(KIND_T, p, (long)p.M * p.s, (long)p.B * p.U, st);
 }
 
@@ -437,6 +510,7 @@ extern "C" int pg_conv1d_wgrad(const pg_conv_args* a, void* stream) {
     p.pt = a->dy; p.pt_bs = a->dy_bs; p.LP = a->Lout; p.act_p = PG_ACT_NONE;
     p.x = a->x; p.x_bs = a->x_bs; p.act_x = a->x_act; p.y = a->dw;
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    if (int e = set_extents(p, p.Q, p.Lx, p.M, p.LP)) return e;
     return launch(KIND_G, p, p.M, (long)p.Q * p.k, (hipStream_t)stream);
 }
 
@@ -448,5 +522,6 @@ extern "C" int pg_convt1d_wgrad(const pg_conv_args* a, void* stream) {
     p.pt = a->x; p.pt_bs = a->x_bs; p.LP = a->Lin; p.act_p = a->x_act;
     p.x = a->dy; p.x_bs = a->dy_bs; p.act_x = PG_ACT_NONE; p.y = a->dw;
     p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    if (int e = set_extents(p, p.Q, p.Lx, p.M, p.LP)) return e;
     return launch(KIND_G, p, p.M, (long)p.Q * p.k, (hipStream_t)stream);
 }
