@@ -109,7 +109,8 @@ int pg_stft(const pg_stft_args* a, void* stream);
 int pg_stft_frame_index(int32_t n_samples, int32_t n_fft, int32_t hop, int32_t n_frames, int32_t* idx, void* stream);
 
 /* data.py:39-47 on its own: in (N,2,...) [re; im] -> out (N,2,...) [log1p|z| ; angle]; inner = bins*frames. */
-typedef struct pg_polar_args { int64_t n_items; int64_t inner; const float* in; float* out; } pg_polar_args;
+typedef struct pg_polar_args { int64_t n_items; int64_t inner; const float* in; float* out;
+                               int32_t use_exp; /* data.py:39 use_exp: 1 -> log1p|z|, 0 -> |z| */ int32_t _pad0; } pg_polar_args;
 int pg_polar(const pg_polar_args* a, void* stream);
 
 /* demo.py:39 + utils.py:34-42: z = (exp(logmag) - 1) e^{j phase} (mode 0) or re + j im (mode 1); zero DC row prepended;

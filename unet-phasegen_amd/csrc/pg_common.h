@@ -22,3 +22,14 @@ __device__ __forceinline__ float pg_block_sum(float v, float* scratch) {
     for (int i = 0; i < nw; ++i) t += scratch[i];
     return t;
 }
+
+// data.py:40 builds z = d[:,0] + d[:,1]*1j from two real arrays.  In IEEE arithmetic that is
+//   imag = 0 + (im*1 + 0*0) = im + 0   (so -0.0 becomes +0.0: a point on the negative real axis with im = -0.0
+//                                        gets angle +pi, not -pi)
+//   real = re + (im*0 - 0*1)           (only the sign of a zero real part can change)
+// Reproduced literally so np.angle parity holds on the branch cut.  (No fast-math: x + 0.0f is not folded.)
+__device__ __forceinline__ void pg_complex_from_parts(float& re, float& im) {
+    const float t = im * 0.0f - 0.0f;
+    re = re + t;
+    im = 0.0f + (im + 0.0f);
+}

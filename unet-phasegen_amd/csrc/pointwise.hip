@@ -162,12 +162,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // ---------------------------------------------------------------------------------------------------------
 // data.py:39-47: [re; im] -> [log1p(|z|); angle(z)], 16 B of traffic per bin-frame.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void polar_kernel(const float* __restrict__ in, float* __restrict__ out, long n_items, long inner) {
+__global__ __launch_bounds__(256) void polar_kernel(const float* __restrict__ in, float* __restrict__ out, long n_items, long inner, int use_exp) {
     const long total = n_items * inner;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long it = e / inner, r = e - it * inner;
-        const float re = in[it * 2 * inner + r], im = in[it * 2 * inner + inner + r];
-        out[it * 2 * inner + r] = log1pf(hypotf(re, im));
+        float re = in[it * 2 * inner + r], im = in[it * 2 * inner + inner + r];
+        pg_complex_from_parts(re, im);
+        const float mag = hypotf(re, im);
+        out[it * 2 * inner + r] = use_exp ? log1pf(mag) : mag;
         out[it * 2 * inner + inner + r] = atan2f(im, re);
     }
 }
@@ -234,6 +236,6 @@ extern "C" int pg_polar(const pg_polar_args* a, void* stream) {
     if (!a || !a->in || !a->out) return pg_fail(PG_ERR_NULL, "polar: in, out required");
     if (a->n_items <= 0 || a->inner <= 0) return pg_fail(PG_ERR_SHAPE, "polar: non-positive size");
     long blocks = (a->n_items * a->inner + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(polar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->in, a->out, (long)a->n_items, (long)a->inner);
+    hipLaunchKernelGGL(polar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->in, a->out, (long)a->n_items, (long)a->inner, a->use_exp);
     return launch_ok("polar launch failed");
 }

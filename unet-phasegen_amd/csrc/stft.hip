@@ -76,8 +76,9 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(const pg_stft_args a)
     float* o_re = a.out + ((long)sig * 2 * bins) * a.n_frames + t;
     float* o_im = o_re + (long)bins * a.n_frames;
     for (int k = 1 + threadIdx.x; k <= bins; k += blockDim.x) {      // bin 0 (DC) dropped, preproc_mdb.py:93
-        const float2 v = X[k];
+        float2 v = X[k];
         if (a.polar) {
+            pg_complex_from_parts(v.x, v.y);
             o_re[(long)(k - 1) * a.n_frames] = log1pf(hypotf(v.x, v.y));
             o_im[(long)(k - 1) * a.n_frames] = atan2f(v.y, v.x);
         } else {

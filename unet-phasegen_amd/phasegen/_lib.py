@@ -57,7 +57,8 @@ class StftArgs(C.Structure):
 
 
 class PolarArgs(C.Structure):
-    _fields_ = [("n_items", C.c_int64), ("inner", C.c_int64), ("inp", C.c_void_p), ("out", C.c_void_p)]
+    _fields_ = [("n_items", C.c_int64), ("inner", C.c_int64), ("inp", C.c_void_p), ("out", C.c_void_p),
+                ("use_exp", C.c_int32), ("_pad0", C.c_int32)]
 
 
 class IstftArgs(C.Structure):

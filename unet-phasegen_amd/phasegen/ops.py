@@ -242,13 +242,14 @@ def stft_frame_index(n_samples, n_fft, hop, device="cuda"):
     return idx
 
 
-def polar(d, out=None):
-    """data.py:39-47: (N, 2, bins, frames) [re; im] -> [log1p|z|; angle]."""
+def polar(d, out=None, use_exp=True):
+    """data.py:39-47: (N, 2, bins, frames) [re; im] -> [log1p|z| (or |z|); angle]."""
     if out is None:
         out = torch.empty_like(d)
     a = _lib.PolarArgs()
     a.n_items, a.inner = d.shape[0], d[0, 0].numel()
     a.inp, a.out = _dense(d, "d"), _dense(out, "out")
+    a.use_exp = int(bool(use_exp))
     _lib.check(_lib.load().pg_polar(C.byref(a), _stream()), "polar")
     return out
 
