@@ -37,12 +37,38 @@ def conv_flops(C, L, B):
     return {n: 2.0 * B * pos * ci * co * k for n, (ci, co, k, pos) in g.items()}
 
 
+def host_threads():
+    """Threads for the CPU leg: the affinity mask / cgroup quota, capped at the GPU box's per-GPU CPU share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN_pmc_summary.json:
+    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc passes of this same command), else None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    for k, v in d.items():
+        if kernel_substr in k and "hbm_read_bytes_corrected" in v:
+            return v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0)
+    return None
+
+
 def cpu_baseline(C, L, max_threads=None):
     """One oracle training step at batch 1 on the host (bounded sample: ~10-40 s of CPU work)."""
     import torch
     from oracle import unet_ref
     from phasegen import detgen
-    threads = max_threads or os.cpu_count()
+    threads = max_threads or host_threads()
     torch.set_num_threads(threads)
     B = 1
     shapes = detgen.conv_shapes(C)
@@ -155,7 +181,9 @@ def main():
                        "final_loss": loss_val},
             "roofline": {"bound": "mfma", "kernel": "conv_t_kernel<32,2> (U0 forward, ConvTranspose1d 4096->2048 k32 s2)",
                          "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": pmc_traffic("conv_t_kernel<32, 2>") if (C, L, B) == (1024, 256, 64) else None,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                          "flops_per_launch": fl["U0"], "ms_per_launch": dom["ms"],
                          "step_tflops": round((3 * sum(fl.values()) - fl["D0"]) / (dt / a.steps) / 1e12, 2)},
             "kernels": ks,

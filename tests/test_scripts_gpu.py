@@ -1,0 +1,42 @@
+"""GPU: the train.py / demo.py counterparts run end to end on synthetic data with the reference's file names and
+printed lines (H2), and a checkpoint written by training loads into the demo."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from phasegen import detgen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "unet-phasegen_amd")
+
+
+def run(args, cwd):
+    r = subprocess.run([sys.executable] + args, cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_train_then_demo(tmp_path):
+    from oracle import signal_ref
+    C, L, n_fft, hop = 16, 24, 32, 8
+    os.makedirs(tmp_path / "dataset")
+    clips = [detgen.make_clip(hop * (L - 1), seed=70 + i) for i in range(6)]
+    arr = np.stack([signal_ref.chunk_and_stft(c, n_fft, hop) for c in clips]).astype(np.float32)     # (N, 2, 16, 24) as preproc writes
+    np.save(tmp_path / "dataset" / "Pop_audio_train.npy", arr)
+    np.save(tmp_path / "dataset" / "Pop_audio_val.npy", arr[:3])
+    out = run([os.path.join(PKG, "train.py"), "--channels", str(C), "--batch_size", "2", "--max_steps", "6", "--ckpt_every", "4",
+               "--log_dir", "unet_llr/"], cwd=str(tmp_path))
+    assert "start loading" in out and "Epoch 1 done," in out and "mag loss:" in out and "ang loss:" in out
+    ckpt = tmp_path / "unet_llr" / "ckpt_4"
+    assert ckpt.exists() and (tmp_path / "unet_llr" / "log.jsonl").exists()
+    out = run([os.path.join(PKG, "demo.py"), "--genre", "Pop", "--n_songs", "2", "--n_fft", str(n_fft), "--hop", str(hop),
+               "--weight", str(ckpt), "--channels", str(C)], cwd=str(tmp_path))
+    assert "UNet - avg" in out and "sec per clip." in out
+    from scipy.io import wavfile
+    for c in range(2):
+        sr, a = wavfile.read(tmp_path / "demo" / f"unet_Pop_{c}.wav")
+        assert sr == 16000 and a.dtype == np.float32 and a.shape == (hop * (L - 1),) and abs(np.max(np.abs(a)) - 1) < 1e-5

@@ -19,18 +19,55 @@ import torch.distributed as dist
 
 from . import ops
 from .optim import Adam
-from .unet import BACKWARD_ORDER
+from .unet import BACKWARD_ORDER, BN_OF, LAYERS
 
 
 class GradBuckets:
-    """Contiguous arena ranges, one per layer, in the order backward completes them."""
+    """Contiguous gradient-arena ranges, one per layer, in the order backward completes them (U0 ... D0)."""
 
-    def __init__(self, engine):
-        self.spans = {name: engine.arena.span(engine.layer_param_keys(name)) for name in BACKWARD_ORDER}
+    def __init__(self, arena):
+        self.arena = arena
+        self.spans = {}
+        for name in BACKWARD_ORDER:
+            keys = [LAYERS[name][0]]
+            if name in BN_OF:
+                keys += [BN_OF[name] + ".weight", BN_OF[name] + ".bias"]
+            self.spans[name] = arena.span(keys)
 
-    def view(self, arena_grad, name):
+    def view(self, name):
         s, e = self.spans[name]
-        return arena_grad[s:e]
+        return self.arena.grad[s:e]
+
+    def covers_arena(self):
+        """True when the buckets tile the whole arena exactly once (no parameter missed, none reduced twice)."""
+        ivs = sorted(self.spans.values())
+        return ivs[0][0] == 0 and ivs[-1][1] == self.arena.numel and all(a[1] == b[0] for a, b in zip(ivs, ivs[1:]))
+
+
+class BucketedAllReduce:
+    """Asynchronous per-layer gradient all-reduce (sum) over torch.distributed -- RCCL over xGMI when the process
+    group's backend is "nccl", gloo in the CPU tests.  ``launch(layer)`` is called from inside backward right after
+    the layer's wgrad has been enqueued; ``wait_all()`` before the optimiser step.  The 1/world averaging is NOT
+    applied here: Adam folds it into its single pass over the arena (grad_scale)."""
+
+    def __init__(self, arena, group=None):
+        self.buckets = GradBuckets(arena)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.pending = []
+        self.launched = []
+
+    def launch(self, name):
+        self.launched.append(name)
+        if self.world > 1:
+            self.pending.append(dist.all_reduce(self.buckets.view(name), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait_all(self):
+        for w in self.pending:
+            w.wait()
+        self.pending.clear()
+        done, self.launched = self.launched, []
+        return done
 
 
 class Trainer:
@@ -38,17 +75,11 @@ class Trainer:
         self.model = model
         self.engine = model.engine
         self.optim = Adam(model.parameters(), lr=lr, betas=betas, eps=eps)
-        self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.buckets = GradBuckets(self.engine)
+        self.reducer = BucketedAllReduce(self.engine.arena, group)
+        self.world = self.reducer.world
         self.mag_weight = mag_weight
         self.losses = torch.zeros(3, device=self.engine.device)
         self._dpred = {}
-        self._pending = []
-
-    def _on_ready(self, name):
-        if self.world > 1:
-            self._pending.append(dist.all_reduce(self.buckets.view(self.engine.arena.grad, name), group=self.group, async_op=True))
 
     def step(self, batch):
         """batch: (B, 2, C, L) = [logmag ; angle] on the device.  Returns the device tensor [loss, ang, mag]."""
@@ -57,9 +88,7 @@ class Trainer:
         if dpred is None:
             dpred = self._dpred[pred.shape] = torch.empty_like(pred)
         ops.loss_fwd_bwd(pred, batch, dpred, self.losses, self.mag_weight)
-        self.engine.backward(dpred, self._on_ready)
-        for w in self._pending:
-            w.wait()
-        self._pending.clear()
+        self.engine.backward(dpred, self.reducer.launch)
+        self.reducer.wait_all()
         self.optim.step(grad_scale=1.0 / self.world)
         return self.losses
