@@ -26,8 +26,7 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16, NT = 256;
-constexpr int LDT = BK + 4;               // floats per LDS row (80 B)
-constexpr int TILE = BM * LDT;            // floats per operand tile (10 KB)
+constexpr int TILE = BM * BK;             // floats per operand tile (8 KB); 2 operands x 2 buffers = 32 KB LDS
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -76,19 +75,49 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 struct Acc { f32x16 c[2][2]; };
 
-// One BK=16 slab: 8 x ds_read_b128, then 8 k-pairs x 4 MFMA.
+// ---- LDS tile image --------------------------------------------------------------------------------------------
+// One operand tile = 128 rows x 16 k, UNPADDED (64-B rows), 16-B chunks XOR-swizzled by (row>>2)&3: element (r,k) sits
+// at dword r*16 + ((k>>2) ^ ((r>>2)&3))*4 + (k&3).  Unpadded because LDS-DMA writes 64 consecutive dwords per wave
+// instruction; swizzled so the fragment ds_read_b128 (lanes = 32 consecutive rows, same logical chunk) is
+// conflict-free.  The swizzle is applied on the DMA *source* side: instruction e of wave w fills dwords
+// [(4e+w)*64, +64), i.e. lane L carries row 16e + 4w + (L>>4) and logical chunk ((L>>2)&3) ^ w -- so a thread owns ONE
+// k column (kt) and eight rows, and its (channel, tap) decode is done once per slab.
+__device__ __forceinline__ int dma_kt(int lane, int w) { return ((((lane >> 2) & 3) ^ w) << 2) | (lane & 3); }
+__device__ __forceinline__ int dma_row(int lane, int w, int e) { return 16 * e + 4 * w + (lane >> 4); }
+
+__device__ __forceinline__ void dma4(rsrc_t r, float* lds_wave_uniform, int elem_off, bool ok) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 4, ok ? elem_off * 4 : OOB, 0, 0, 0);
+}
+
+// One BK=16 slab: 8 x ds_read_b128 (swizzled), optional activation on the fragments, 8 k-pairs x 4 MFMA.
 __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs,
-                                         int lane, int wm, int wn, Acc& acc) {
-    const int r = lane & 31, h = lane >> 5;
-    const float* ap = As + (wm * 64 + r) * LDT + h * 8;
-    const float* bp = Bs + (wn * 64 + r) * LDT + h * 8;
+                                         int lane, int wm, int wn, float slopeA, float slopeB, Acc& acc) {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
+    const float* ap = As + (wm * 64 + r) * BK;
+    const float* bp = Bs + (wn * 64 + r) * BK;
     f32x4 a[2][2], b[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        a[i][0] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDT);
-        a[i][1] = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDT + 4);
-        b[i][0] = *reinterpret_cast<const f32x4*>(bp + i * 32 * LDT);
-        b[i][1] = *reinterpret_cast<const f32x4*>(bp + i * 32 * LDT + 4);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+            b[i][c] = *reinterpret_cast<const f32x4*>(bp + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+        }
+    if (slopeA != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a[i][c][v] = act_apply(a[i][c][v], slopeA);
+    }
+    if (slopeB != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) b[i][c][v] = act_apply(b[i][c][v], slopeB);
     }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -98,23 +127,6 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const flo
         acc.c[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.c[0][1], 0, 0, 0);
         acc.c[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.c[1][0], 0, 0, 0);
         acc.c[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.c[1][1], 0, 0, 0);
-    }
-}
-
-// Register-staged tiles: each thread carries 2 x float4 of A and 2 x float4 of B per slab.
-struct Stage { f32x4 a[2], b[2]; };
-
-__device__ __forceinline__ void stage_store(float* As, float* Bs, const Stage& st, int tid, float slopeA, float slopeB) {
-    // A: thread -> (row = tid>>2 (+64), kgroup = tid&3);  B: thread -> (row = tid&127, kgroup = tid>>7 (+2))
-    // Activation happens HERE (after the MFMA block in program order), never at the load, so the gathers of the
-    // next slab stay in flight underneath the matrix work.
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        f32x4 a = st.a[e], b = st.b[e];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = act_apply(a[i], slopeA); b[i] = act_apply(b[i], slopeB); }
-        *reinterpret_cast<f32x4*>(As + ((tid >> 2) + 64 * e) * LDT + (tid & 3) * 4) = a;
-        *reinterpret_cast<f32x4*>(Bs + (tid & 127) * LDT + ((tid >> 7) + 2 * e) * 4) = b;
     }
 }
 
@@ -135,76 +147,66 @@ struct Epi {
     }
 };
 
-#define PG_MAINLOOP(LOAD_A, LOAD_B)                                                     \
+// Main loop shared by the three kernels.  ISSUE(buf, k0) enqueues the 16 LDS-DMA gathers of one slab (8 per operand
+// per thread) into LDS buffer `buf`; there are no staging registers and no ds_write.  The only wait is the vmcnt(0)
+// that __syncthreads() carries, which sits AFTER the slab's 32 MFMAs, so gather latency is covered by matrix work.
+// buf^1 is refilled while buf is read: its previous readers all passed the barrier that ended the last iteration.
+#define PG_MAINLOOP(ISSUE)                                                              \
     __shared__ __attribute__((aligned(16))) float lds[4 * TILE];                        \
     Acc acc;                                                                            \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;            \
-    Stage st;                                                                           \
     const int nslab = (Ktot + BK - 1) / BK;                                             \
-    { const int k0 = 0; LOAD_A; LOAD_B; }                                               \
-    stage_store(lds, lds + TILE, st, tid, slopeA, slopeB);                                              \
+    { float* const As = lds + wv * 64; float* const Bs = As + TILE; const int k0 = 0; ISSUE }  \
     __syncthreads();                                                                    \
     for (int sl = 0; sl < nslab; ++sl) {                                                \
         const int cur = sl & 1;                                                         \
-        const int k0 = (sl + 1) * BK;      /* past-the-end slab loads only zeros */     \
-        LOAD_A; LOAD_B;                                                                 \
-        mma_slab(lds + cur * 2 * TILE, lds + cur * 2 * TILE + TILE, lane, wm, wn, acc); \
-        stage_store(lds + (cur ^ 1) * 2 * TILE, lds + (cur ^ 1) * 2 * TILE + TILE, st, tid, slopeA, slopeB); \
+        { float* const As = lds + (cur ^ 1) * 2 * TILE + wv * 64; float* const Bs = As + TILE; \
+          const int k0 = (sl + 1) * BK;    /* past-the-end slab gathers only zeros */   \
+          ISSUE }                                                                       \
+        __builtin_amdgcn_sched_barrier(0);  /* gathers are issued BEFORE the matrix work ... */ \
+        mma_slab(lds + cur * 2 * TILE, lds + cur * 2 * TILE + TILE, lane, wm, wn, slopeA, slopeB, acc); \
+        __builtin_amdgcn_sched_barrier(0);  /* ... which stays in front of the barrier's vmcnt(0) */ \
         __syncthreads();                                                                \
     }
+
+#define PG_PROLOGUE                                                                                 \
+    const int tid = threadIdx.x, lane = tid & 63;                                                   \
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;             \
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);                                              \
+    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;                             \
+    const int kw = KW ? KW : p.k, s = S ? S : p.s;                                                  \
+    const int kt = dma_kt(lane, wv);
+
+constexpr int NEVER = 0x40000000;   // a "first valid tap/position" no index ever reaches: marks rows outside the tile
 
 // ------------------------------------------------------------------------------------------------------------
 // F kernel
 // ------------------------------------------------------------------------------------------------------------
 template <int KW, int S>
 __global__ __launch_bounds__(NT) void conv_f_kernel(const IgemmParams p) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
-    const int kw = KW ? KW : p.k, s = S ? S : p.s;
+    PG_PROLOGUE
     const int Ktot = p.Q * kw, Ntot = p.B * p.Ly;
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
-
-    // A operand (weights, K-contiguous rows): thread -> rows (tid>>2) + 64e, k-group tid&3
-    int arow[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int m = m0 + (tid >> 2) + 64 * e;
-        arow[e] = m < p.M ? m * Ktot + (tid & 3) * 4 : -1;
-    }
-    // B operand (im2col): one output position n per thread
-    const int nB = n0 + (tid & 127);
-    const bool nvalid = nB < Ntot;
-    const int bB = nvalid ? nB / p.Ly : 0, tB = nvalid ? nB - bB * p.Ly : 0;
-    const int xoff = bB * (int)p.x_bs + s * tB - p.p;          // element offset of tap j = 0, channel 0
-    const int jlo = p.p - s * tB;                              // valid taps: 0 <= j - jlo < Lx
-    const unsigned jspan = nvalid ? (unsigned)p.Lx : 0u;
     const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
-
-#define F_LOAD_A                                                                                   \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-        const int kk = k0 + (tid & 3) * 4;                                                         \
-        if (p.a_vec) {                                                                             \
-            const bool ok = arow[e] >= 0 && kk < Ktot;                                             \
-            st.a[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? (arow[e] + k0) * 4 : OOB, 0, 0)); \
-        } else {                                                                                   \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
-                st.a[e][i] = bload(rw, arow[e] + k0 + i, arow[e] >= 0 && kk + i < Ktot);           \
-        }                                                                                          \
+    int aoff[8], xoff[8], jlo[8];      // per-row constants of this thread's 8 A rows / 8 B rows
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);
+        aoff[e] = m < p.M ? m * Ktot + kt : -1;
+        const bool nv = n < Ntot;
+        const int b = nv ? n / p.Ly : 0, t = nv ? n - b * p.Ly : 0;
+        xoff[e] = b * (int)p.x_bs + s * t - p.p;        // element offset of tap 0, channel 0
+        jlo[e] = nv ? p.p - s * t : NEVER;              // taps with 0 <= j - jlo < Lx are inside the row
     }
-#define F_LOAD_B                                                                                   \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-        const int kk0 = k0 + ((tid >> 7) + 2 * e) * 4;                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            const int kk = kk0 + i, q = kk / kw, j = kk - q * kw;                                  \
-            const bool ok = kk < Ktot && (unsigned)(j - jlo) < jspan;                              \
-            st.b[e][i] = bload(rx, xoff + q * p.Lx + j, ok);                       \
-        }                                                                                          \
-    }
-    PG_MAINLOOP(F_LOAD_A, F_LOAD_B)
-#undef F_LOAD_A
-#undef F_LOAD_B
+#define F_ISSUE                                                                                       \
+    { const int kk = k0 + kt, q = kk / kw, j = kk - q * kw, xq = q * p.Lx + j; const bool kok = kk < Ktot; \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
+          dma4(rw, As + e * 256, aoff[e] + k0, kok && aoff[e] >= 0);                                  \
+          dma4(rx, Bs + e * 256, xoff[e] + xq, kok && (unsigned)(j - jlo[e]) < (unsigned)p.Lx);       \
+      } }
+    PG_MAINLOOP(F_ISSUE)
+#undef F_ISSUE
 
     // epilogue: acc reg r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
     const Epi ep(p, (unsigned)((long)p.M * p.Ly * 4));
@@ -234,52 +236,33 @@ __global__ __launch_bounds__(NT) void conv_f_kernel(const IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------
 template <int KW, int S>
 __global__ __launch_bounds__(NT) void conv_t_kernel(const IgemmParams p) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
-    const int kw = KW ? KW : p.k, s = S ? S : p.s;
+    PG_PROLOGUE
     const int KJ = (kw + s - 1) / s;
     const int Ktot = p.Q * KJ, Ntot = p.B * p.U, Mrows = p.M * s;
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
-    const int wq = p.M * kw;                  // weight stride between input channels q
-
-    // A operand: W[q][o][s*jj + phi]; thread -> rows m' = (tid>>2) + 64e (o = m'/s, phi = m'%s), k-group tid&3
-    int arow[2], aphi[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int mr = m0 + (tid >> 2) + 64 * e, o = mr / s;
-        aphi[e] = mr - o * s;
-        arow[e] = mr < Mrows ? o * kw + aphi[e] : -1;
-    }
-    // B operand: X[b][q][u - jj]; one (b, u) per thread
-    const int nB = n0 + (tid & 127);
-    const bool nvalid = nB < Ntot;
-    const int bB = nvalid ? nB / p.U : 0, uB = (nvalid ? nB - bB * p.U : 0) + p.u_off;
-    const int xoff = bB * (int)p.x_bs + uB;
-    const unsigned xspan = nvalid ? (unsigned)p.Lx : 0u;
     const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
-
-#define T_LOAD_A                                                                                   \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-        const int kk0 = k0 + (tid & 3) * 4;                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            const int kk = kk0 + i, q = kk / KJ, jj = kk - q * KJ;                                 \
-            const bool ok = arow[e] >= 0 && kk < Ktot && s * jj + aphi[e] < kw;                    \
-            st.a[e][i] = bload(rw, q * wq + arow[e] + s * jj, ok);                                 \
-        }                                                                                          \
+    const int wq = p.M * kw;                  // weight stride between input channels q
+    int aoff[8], jmax[8], xoff[8], ub[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int mr = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);
+        const int o = mr / s, phi = mr - o * s;
+        aoff[e] = mr < Mrows ? o * kw + phi : -1;       // W[q][o][s*jj + phi]
+        jmax[e] = kw - phi;                             // tap exists iff s*jj < kw - phi
+        const bool nv = n < Ntot;
+        const int b = nv ? n / p.U : 0, u = (nv ? n - b * p.U : 0) + p.u_off;
+        xoff[e] = b * (int)p.x_bs + u;                  // X[b][q][u - jj]
+        ub[e] = nv ? u : -NEVER;                        // position u - jj must lie in [0, Lx)
     }
-#define T_LOAD_B                                                                                   \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-        const int kk0 = k0 + ((tid >> 7) + 2 * e) * 4;                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            const int kk = kk0 + i, q = kk / KJ, jj = kk - q * KJ;                                 \
-            const bool ok = kk < Ktot && (unsigned)(uB - jj) < xspan;                              \
-            st.b[e][i] = bload(rx, xoff + q * p.Lx - jj, ok);                      \
-        }                                                                                          \
-    }
-    PG_MAINLOOP(T_LOAD_A, T_LOAD_B)
-#undef T_LOAD_A
-#undef T_LOAD_B
+#define T_ISSUE                                                                                       \
+    { const int kk = k0 + kt, q = kk / KJ, jj = kk - q * KJ, wo = q * wq + s * jj, xq = q * p.Lx - jj; \
+      const bool kok = kk < Ktot;                                                                     \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
+          dma4(rw, As + e * 256, aoff[e] + wo, kok && aoff[e] >= 0 && s * jj < jmax[e]);              \
+          dma4(rx, Bs + e * 256, xoff[e] + xq, kok && (unsigned)(ub[e] - jj) < (unsigned)p.Lx);       \
+      } }
+    PG_MAINLOOP(T_ISSUE)
+#undef T_ISSUE
 
     const Epi ep(p, (unsigned)((long)p.M * p.Ly * 4));
 #pragma unroll
@@ -317,53 +300,30 @@ __device__ __forceinline__ void divmod24(int n, int d, float inv, int& q, int& r
 
 template <int KW, int S>
 __global__ __launch_bounds__(NT) void conv_g_kernel(const IgemmParams p) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
-    const int kw = KW ? KW : p.k, s = S ? S : p.s;
+    PG_PROLOGUE
     const int Ktot = p.B * p.LP, Ntot = p.Q * kw;
     const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
-
-    // A operand: P[b][m][i]; thread -> rows (tid>>2) + 64e, k-group tid&3
-    int arow[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int m = m0 + (tid >> 2) + 64 * e;
-        arow[e] = m < p.M ? m * p.LP : -1;
-    }
-    // B operand: Q[b][q][s*i + j - p]; one (q, j) per thread
-    const int nB = n0 + (tid & 127);
-    const bool nvalid = nB < Ntot;
-    const int qB = nvalid ? nB / kw : 0, jB = nvalid ? nB - qB * kw : 0;
-    const int xoff = qB * p.Lx + jB - p.p;
-    const unsigned xspan = nvalid ? (unsigned)p.Lx : 0u;
     const float slopeA = act_slope(p.act_p), slopeB = act_slope(p.act_x);
     const int pbs = (int)p.pt_bs, xbs = (int)p.x_bs;
-
-#define G_LOAD_A                                                                                   \
-    {                                                                                              \
-        int bb, ii;                                                                                \
-        divmod24(k0 + (tid & 3) * 4, p.LP, p.inv_LP, bb, ii);                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            const bool okb = bb < p.B;                                                             \
-            _Pragma("unroll") for (int e = 0; e < 2; ++e)                                          \
-                st.a[e][i] = bload(rp, bb * pbs + arow[e] + ii, okb && arow[e] >= 0); \
-            ++ii; if (ii == p.LP) { ii = 0; ++bb; }                                                \
-        }                                                                                          \
+    int aoff[8], xoff[8], jp[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);
+        aoff[e] = m < p.M ? m * p.LP : -1;              // P[b][m][i]
+        const bool nv = n < Ntot;
+        const int q = nv ? n / kw : 0, j = nv ? n - q * kw : 0;
+        xoff[e] = q * p.Lx + j - p.p;                   // Q[b][q][s*i + j - p]
+        jp[e] = nv ? j - p.p : -NEVER;
     }
-#define G_LOAD_B                                                                                   \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-        int bb, ii;                                                                                \
-        divmod24(k0 + ((tid >> 7) + 2 * e) * 4, p.LP, p.inv_LP, bb, ii);                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-            const bool ok = bb < p.B && (unsigned)(s * ii + jB - p.p) < xspan;                     \
-            st.b[e][i] = bload(rx, bb * xbs + xoff + s * ii, ok);                 \
-            ++ii; if (ii == p.LP) { ii = 0; ++bb; }                                                \
-        }                                                                                          \
-    }
-    PG_MAINLOOP(G_LOAD_A, G_LOAD_B)
-#undef G_LOAD_A
-#undef G_LOAD_B
+#define G_ISSUE                                                                                       \
+    { int bb, ii; divmod24(k0 + kt, p.LP, p.inv_LP, bb, ii);                                          \
+      const bool kok = bb < p.B; const int po = bb * pbs + ii, xo = bb * xbs + s * ii;                \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
+          dma4(rp, As + e * 256, aoff[e] + po, kok && aoff[e] >= 0);                                  \
+          dma4(rx, Bs + e * 256, xoff[e] + xo, kok && (unsigned)(s * ii + jp[e]) < (unsigned)p.Lx);   \
+      } }
+    PG_MAINLOOP(G_ISSUE)
+#undef G_ISSUE
 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
