@@ -48,7 +48,12 @@ typedef struct pg_conv_args {
     int32_t dx_mask; int32_t _pad1;
     float* dw;                       /* grad wrt w, same layout as w; OVERWRITTEN by *_wgrad (beta = 0:     */
                                      /*   optim.zero_grad(), train.py:41, is folded into the write)         */
+    void* workspace; int64_t workspace_bytes; /* optional scratch (pg_workspace_bytes_conv()): lets tile counts   */
+                                     /*   that quantise badly over the CUs be split evenly (stream-K);      */
+                                     /*   contents are garbage between calls; NULL = always one tile per WG */
 } pg_conv_args;
+int64_t pg_workspace_bytes_conv(void);
+int pg_conv_set_schedule(int mode);  /* test hook: 0 auto, 1 one tile per workgroup, 2 force stream-K       */
 
 /* nn.Conv1d forward / backward (model.py:77-78; autograd of train.py:61) */
 int pg_conv1d_fwd(const pg_conv_args* a, void* stream);

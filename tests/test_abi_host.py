@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     from phasegen import _lib
     lib = _lib.load()
     names = declared_symbols()
-    assert len(names) >= 19 and "pg_conv1d_fwd" in names and "pg_istft" in names
+    assert len(names) >= 21 and "pg_conv1d_fwd" in names and "pg_istft" in names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in phasegen.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_the_header_layout():
     from phasegen import _lib
-    assert ctypes.sizeof(_lib.ConvArgs) == 8 * 4 + 8 + 8 + 4 + 4 + 8 + 4 * 16 + 8 + 8 + 8 + 8   # 168
+    assert ctypes.sizeof(_lib.ConvArgs) == 8 * 4 + 8 + 8 + 4 + 4 + 8 + 4 * 16 + 8 + 8 + 8 + 8 + 16   # 184
     assert ctypes.sizeof(_lib.AdamArgs) == 8 + 4 * 8 + 5 * 8 + 8
     assert ctypes.sizeof(_lib.LossArgs) == 16 + 4 * 8 + 8 + 8
 

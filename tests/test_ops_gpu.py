@@ -39,9 +39,20 @@ GEOMS = [
 ]
 
 
+@pytest.fixture(params=[1, 2], ids=["tile-per-wg", "stream-k"])
+def schedule(request):
+    """Run the conv tests under both work decompositions: one whole tile per workgroup, and the persistent stream-K
+    split (partial tiles through the workspace + fixup kernel), which the library otherwise only picks for tile
+    counts that quantise badly over the CUs."""
+    from phasegen import ops
+    ops.set_conv_schedule(request.param)
+    yield request.param
+    ops.set_conv_schedule(0)
+
+
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("act", [0, 1, 2])
-def test_conv_fwd_dgrad_wgrad(geom, act):
+def test_conv_fwd_dgrad_wgrad(geom, act, schedule):
     from phasegen import ops
     tr, Cin, Cout, k, s, p, Lin, B = geom
     x = rnd(1, B, Cin, Lin)
@@ -76,7 +87,7 @@ def test_conv_fwd_dgrad_wgrad(geom, act):
     assert relerr(dw, wr.grad) < TOL
 
 
-def test_conv_on_concat_slices():
+def test_conv_on_concat_slices(schedule):
     """Operands given as channel slices of a wider buffer (batch stride != C*L), as the U-Net concat does."""
     from phasegen import ops
     B, C, L = 3, 24, 29
@@ -169,3 +180,21 @@ def test_bad_arguments_raise():
         ops.conv_fwd(x.transpose(1, 2), w, torch.zeros(2, 16, 13, device="cuda"), 2, 16)  # not frame-contiguous
     with pytest.raises(RuntimeError):
         ops.adam_step(x.view(-1), x.view(-1), x.view(-1), x.view(-1), 0)        # step is 1-based
+
+
+def test_stream_k_is_bit_identical_run_to_run_and_matches_plain_closely():
+    """The stream-K split sums partial tiles in a fixed order: two runs are bit-identical; against the one-tile-per-
+    workgroup schedule only the k-summation order differs (fp32 rounding)."""
+    from phasegen import ops
+    B, Cin, Cout, k, s, p, Lin = 5, 96, 200, 8, 2, 1, 61
+    x, w = rnd(41, B, Cin, Lin).cuda(), (rnd(42, Cout, Cin, k) * 0.1).cuda()
+    Lout = ops.conv_out_len(Lin, k, s, p)
+    outs = []
+    for mode in (2, 2, 1):
+        ops.set_conv_schedule(mode)
+        y = torch.empty(B, Cout, Lout, device="cuda")
+        ops.conv_fwd(x, w, y, s, p, x_act=1)
+        outs.append(y.clone())
+    ops.set_conv_schedule(0)
+    assert torch.equal(outs[0], outs[1])
+    assert relerr(outs[0], outs[2]) < 1e-5

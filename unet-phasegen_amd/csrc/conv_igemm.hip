@@ -45,6 +45,8 @@ struct IgemmParams {
     int LP; float inv_LP;            // G: frames of P and 1/LP
     int a_vec;                       // F: weight rows may be read as aligned float4
     int tilesM, tilesN;
+    float* ws;                       // stream-K partial-tile workspace: [grid][2][64][256] floats (or NULL)
+    int nslab;                       // K slabs per tile
 };
 
 // Activations are applied branch-free as max(v,0) + slope*min(v,0): slope 1 = identity, 0.2 = LeakyReLU(0.2)
@@ -147,68 +149,39 @@ struct Epi {
     }
 };
 
-// Main loop shared by the three kernels.  ISSUE(buf, k0) enqueues the 16 LDS-DMA gathers of one slab (8 per operand
-// per thread) into LDS buffer `buf`; there are no staging registers and no ds_write.  The only wait is the vmcnt(0)
-// that __syncthreads() carries, which sits AFTER the slab's 32 MFMAs, so gather latency is covered by matrix work.
-// buf^1 is refilled while buf is read: its previous readers all passed the barrier that ended the last iteration.
-#define PG_MAINLOOP(ISSUE)                                                              \
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];                        \
-    Acc acc;                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;            \
-    const int nslab = (Ktot + BK - 1) / BK;                                             \
-    { float* const As = lds + wv * 64; float* const Bs = As + TILE; const int k0 = 0; ISSUE }  \
-    __syncthreads();                                                                    \
-    for (int sl = 0; sl < nslab; ++sl) {                                                \
-        const int cur = sl & 1;                                                         \
-        { float* const As = lds + (cur ^ 1) * 2 * TILE + wv * 64; float* const Bs = As + TILE; \
-          const int k0 = (sl + 1) * BK;    /* past-the-end slab gathers only zeros */   \
-          ISSUE }                                                                       \
-        __builtin_amdgcn_sched_barrier(0);  /* gathers are issued BEFORE the matrix work ... */ \
-        mma_slab(lds + cur * 2 * TILE, lds + cur * 2 * TILE + TILE, lane, wm, wn, slopeA, slopeB, acc); \
-        __builtin_amdgcn_sched_barrier(0);  /* ... which stays in front of the barrier's vmcnt(0) */ \
-        __syncthreads();                                                                \
-    }
+// ---- work decomposition (stream-K) -------------------------------------------------------------------------------
+// The launch is a grid of G workgroups over the linearised (tile, slab) space of tiles*nslab units; workgroup g owns
+// the contiguous range [lo(g), lo(g+1)).  With G == tiles every workgroup owns exactly one whole tile (the plain
+// data-parallel GEMM).  With G == resident workgroup slots (host picks that when the tile count quantises badly over
+// 256 CUs, e.g. 1040 tiles) every CU gets the same number of MFMAs: a range then starts / ends inside tiles, those
+// segments leave their accumulators in the workspace (slot 0 = the range's first segment, slot 1 = its last) and the
+// fixup kernel adds a tile's segments in ascending workgroup order and runs the epilogue.  No atomics, no flags, no
+// inter-workgroup ordering assumption: results are bit-reproducible.
+struct Split { int total, q, r; };
+__device__ __host__ __forceinline__ Split make_split(int tiles, int nslab, int G) {
+    Split sp; sp.total = tiles * nslab; sp.q = sp.total / G; sp.r = sp.total - sp.q * G; return sp;
+}
+__device__ __host__ __forceinline__ int split_lo(const Split& sp, int g) { return g < sp.r ? g * (sp.q + 1) : sp.r * (sp.q + 1) + (g - sp.r) * sp.q; }
+__device__ __host__ __forceinline__ int split_owner(const Split& sp, int x) {
+    const int big = sp.r * (sp.q + 1);
+    return x < big ? x / (sp.q + 1) : sp.r + (x - big) / sp.q;
+}
 
-#define PG_PROLOGUE                                                                                 \
-    const int tid = threadIdx.x, lane = tid & 63;                                                   \
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;             \
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);                                              \
-    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;                             \
-    const int kw = KW ? KW : p.k, s = S ? S : p.s;                                                  \
-    const int kt = dma_kt(lane, wv);
-
-constexpr int NEVER = 0x40000000;   // a "first valid tap/position" no index ever reaches: marks rows outside the tile
-
-// ------------------------------------------------------------------------------------------------------------
-// F kernel
-// ------------------------------------------------------------------------------------------------------------
-template <int KW, int S>
-__global__ __launch_bounds__(NT) void conv_f_kernel(const IgemmParams p) {
-    PG_PROLOGUE
-    const int Ktot = p.Q * kw, Ntot = p.B * p.Ly;
-    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
-    const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
-    int aoff[8], xoff[8], jlo[8];      // per-row constants of this thread's 8 A rows / 8 B rows
+__device__ __forceinline__ void store_partial(float* ws, int g, int slot, const Acc& acc, int tid) {
+    float* dst = ws + ((long)(g * 2 + slot) * 64) * NT + tid;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);
-        aoff[e] = m < p.M ? m * Ktot + kt : -1;
-        const bool nv = n < Ntot;
-        const int b = nv ? n / p.Ly : 0, t = nv ? n - b * p.Ly : 0;
-        xoff[e] = b * (int)p.x_bs + s * t - p.p;        // element offset of tap 0, channel 0
-        jlo[e] = nv ? p.p - s * t : NEVER;              // taps with 0 <= j - jlo < Lx are inside the row
-    }
-#define F_ISSUE                                                                                       \
-    { const int kk = k0 + kt, q = kk / kw, j = kk - q * kw, xq = q * p.Lx + j; const bool kok = kk < Ktot; \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
-          dma4(rw, As + e * 256, aoff[e] + k0, kok && aoff[e] >= 0);                                  \
-          dma4(rx, Bs + e * 256, xoff[e] + xq, kok && (unsigned)(j - jlo[e]) < (unsigned)p.Lx);       \
-      } }
-    PG_MAINLOOP(F_ISSUE)
-#undef F_ISSUE
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((i * 2 + j) * 16 + r) * NT] = acc.c[i][j][r];
+}
 
-    // epilogue: acc reg r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+// ---- epilogues (shared by the GEMM kernels and the fixup kernels) -------------------------------------------------
+// acc reg r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+template <int S>
+__device__ __forceinline__ void epilogue_f(const IgemmParams& p, const Acc& acc, int m0, int n0, int lane, int wm, int wn) {
+    const int Ntot = p.B * p.Ly;
     const Epi ep(p, (unsigned)((long)p.M * p.Ly * 4));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -231,39 +204,10 @@ __global__ __launch_bounds__(NT) void conv_f_kernel(const IgemmParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// T kernel.  GEMM rows m' = o*s + phi, K = (q, jj) with KJ = ceil(k/s) taps per phase, N = (b, u).
-// ------------------------------------------------------------------------------------------------------------
-template <int KW, int S>
-__global__ __launch_bounds__(NT) void conv_t_kernel(const IgemmParams p) {
-    PG_PROLOGUE
-    const int KJ = (kw + s - 1) / s;
-    const int Ktot = p.Q * KJ, Ntot = p.B * p.U, Mrows = p.M * s;
-    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
-    const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
-    const int wq = p.M * kw;                  // weight stride between input channels q
-    int aoff[8], jmax[8], xoff[8], ub[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int mr = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);
-        const int o = mr / s, phi = mr - o * s;
-        aoff[e] = mr < Mrows ? o * kw + phi : -1;       // W[q][o][s*jj + phi]
-        jmax[e] = kw - phi;                             // tap exists iff s*jj < kw - phi
-        const bool nv = n < Ntot;
-        const int b = nv ? n / p.U : 0, u = (nv ? n - b * p.U : 0) + p.u_off;
-        xoff[e] = b * (int)p.x_bs + u;                  // X[b][q][u - jj]
-        ub[e] = nv ? u : -NEVER;                        // position u - jj must lie in [0, Lx)
-    }
-#define T_ISSUE                                                                                       \
-    { const int kk = k0 + kt, q = kk / KJ, jj = kk - q * KJ, wo = q * wq + s * jj, xq = q * p.Lx - jj; \
-      const bool kok = kk < Ktot;                                                                     \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
-          dma4(rw, As + e * 256, aoff[e] + wo, kok && aoff[e] >= 0 && s * jj < jmax[e]);              \
-          dma4(rx, Bs + e * 256, xoff[e] + xq, kok && (unsigned)(ub[e] - jj) < (unsigned)p.Lx);       \
-      } }
-    PG_MAINLOOP(T_ISSUE)
-#undef T_ISSUE
-
+template <int S>
+__device__ __forceinline__ void epilogue_t(const IgemmParams& p, const Acc& acc, int m0, int n0, int lane, int wm, int wn) {
+    const int s = S ? S : p.s;
+    const int Ntot = p.B * p.U, Mrows = p.M * s;
     const Epi ep(p, (unsigned)((long)p.M * p.Ly * 4));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -287,44 +231,9 @@ __global__ __launch_bounds__(NT) void conv_t_kernel(const IgemmParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// G kernel.  dW[m][(q,j)] = sum over kk = (b,i) of actP(P[b,m,i]) * actQ(Q[b,q,s*i+j-p]);  Q tensor is p.x.
-// ------------------------------------------------------------------------------------------------------------
-// n / d for 0 <= n < 2^24 via the float reciprocal, exact after one correction step (branch-free selects).
-__device__ __forceinline__ void divmod24(int n, int d, float inv, int& q, int& r) {
-    q = (int)((float)n * inv);
-    r = n - q * d;
-    if (r < 0) { r += d; --q; }
-    if (r >= d) { r -= d; ++q; }
-}
-
-template <int KW, int S>
-__global__ __launch_bounds__(NT) void conv_g_kernel(const IgemmParams p) {
-    PG_PROLOGUE
-    const int Ktot = p.B * p.LP, Ntot = p.Q * kw;
-    const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
-    const float slopeA = act_slope(p.act_p), slopeB = act_slope(p.act_x);
-    const int pbs = (int)p.pt_bs, xbs = (int)p.x_bs;
-    int aoff[8], xoff[8], jp[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);
-        aoff[e] = m < p.M ? m * p.LP : -1;              // P[b][m][i]
-        const bool nv = n < Ntot;
-        const int q = nv ? n / kw : 0, j = nv ? n - q * kw : 0;
-        xoff[e] = q * p.Lx + j - p.p;                   // Q[b][q][s*i + j - p]
-        jp[e] = nv ? j - p.p : -NEVER;
-    }
-#define G_ISSUE                                                                                       \
-    { int bb, ii; divmod24(k0 + kt, p.LP, p.inv_LP, bb, ii);                                          \
-      const bool kok = bb < p.B; const int po = bb * pbs + ii, xo = bb * xbs + s * ii;                \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
-          dma4(rp, As + e * 256, aoff[e] + po, kok && aoff[e] >= 0);                                  \
-          dma4(rx, Bs + e * 256, xoff[e] + xo, kok && (unsigned)(s * ii + jp[e]) < (unsigned)p.Lx);   \
-      } }
-    PG_MAINLOOP(G_ISSUE)
-#undef G_ISSUE
-
+template <int S>
+__device__ __forceinline__ void epilogue_g(const IgemmParams& p, const Acc& acc, int m0, int n0, int lane, int wm, int wn) {
+    const int Ntot = p.Q * p.k;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
@@ -337,6 +246,186 @@ __global__ __launch_bounds__(NT) void conv_g_kernel(const IgemmParams p) {
                 if (m < p.M) p.y[(long)m * Ntot + n] = acc.c[i][j][r];
             }
     }
+}
+
+// Body shared by the three GEMM kernels.  SETUP computes this thread's per-row gather constants for tile (m0, n0);
+// ISSUE enqueues the 16 LDS-DMA gathers of one slab (8 per operand per thread) into the LDS buffer (As, Bs): there are
+// no staging registers and no ds_write.  The only wait is the vmcnt(0) that __syncthreads() carries, and it sits AFTER
+// the slab's 32 MFMAs (phase order pinned with sched_barrier: hipcc otherwise hoists the register-only MFMAs above the
+// gather issue), so gather latency is covered by matrix work.  buf^1 is refilled while buf is read: its previous
+// readers all passed the barrier that ended the last iteration.
+#define PG_BODY(SETUP, ISSUE, EPILOGUE)                                                             \
+    const int tid = threadIdx.x, lane = tid & 63;                                                   \
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;             \
+    const int kw = KW ? KW : p.k, s = S ? S : p.s;                                                  \
+    const int kt = dma_kt(lane, wv);                                                                \
+    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];                                    \
+    const int g = xcd_remap(blockIdx.x, gridDim.x);                                                 \
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);                           \
+    int pos = split_lo(sp, g);                                                                      \
+    const int pos_end = split_lo(sp, g + 1);                                                        \
+    int slot = 0;                                                                                   \
+    while (pos < pos_end) {                                                                         \
+        const int tile = pos / p.nslab, sb = pos - tile * p.nslab;                                  \
+        const int se = min(p.nslab, sb + (pos_end - pos));                                          \
+        const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;                         \
+        SETUP                                                                                       \
+        Acc acc;                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;                    \
+        { float* const As = lds + wv * 64; float* const Bs = As + TILE; const int k0 = sb * BK; ISSUE } \
+        __syncthreads();                                                                            \
+        for (int sl = sb; sl < se; ++sl) {                                                          \
+            const int cur = (sl - sb) & 1;                                                          \
+            { float* const As = lds + (cur ^ 1) * 2 * TILE + wv * 64; float* const Bs = As + TILE;  \
+              const int k0 = (sl + 1) * BK;    /* past-the-end slab gathers only zeros */           \
+              ISSUE }                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            mma_slab(lds + cur * 2 * TILE, lds + cur * 2 * TILE + TILE, lane, wm, wn, slopeA, slopeB, acc); \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            __syncthreads();                                                                        \
+        }                                                                                           \
+        if (sb == 0 && se == p.nslab) { EPILOGUE }                                                  \
+        else store_partial(p.ws, g, slot, acc, tid);                                                \
+        pos += se - sb;                                                                             \
+        slot = 1;                                                                                   \
+    }
+
+constexpr int NEVER = 0x40000000;   // a "first valid tap/position" no index ever reaches: marks rows outside the tile
+
+// ------------------------------------------------------------------------------------------------------------
+// F kernel
+// ------------------------------------------------------------------------------------------------------------
+template <int KW, int S>
+__global__ __launch_bounds__(NT, 3) void conv_f_kernel(const IgemmParams p) {
+    const int Ktot = p.Q * (KW ? KW : p.k), Ntot = p.B * p.Ly;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
+#define F_SETUP                                                                                       \
+    int aoff[8], xoff[8], jlo[8];      /* per-row constants of this thread's 8 A rows / 8 B rows */    \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
+        const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);                       \
+        aoff[e] = m < p.M ? m * Ktot + kt : -1;                                                       \
+        const bool nv = n < Ntot;                                                                     \
+        const int b = nv ? n / p.Ly : 0, t = nv ? n - b * p.Ly : 0;                                   \
+        xoff[e] = b * (int)p.x_bs + s * t - p.p;        /* element offset of tap 0, channel 0 */      \
+        jlo[e] = nv ? p.p - s * t : NEVER;              /* taps with 0 <= j - jlo < Lx are inside the row */ \
+    }
+#define F_ISSUE                                                                                       \
+    { const int kk = k0 + kt, q = kk / kw, j = kk - q * kw, xq = q * p.Lx + j; const bool kok = kk < Ktot; \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
+          dma4(rw, As + e * 256, aoff[e] + k0, kok && aoff[e] >= 0);                                  \
+          dma4(rx, Bs + e * 256, xoff[e] + xq, kok && (unsigned)(j - jlo[e]) < (unsigned)p.Lx);       \
+      } }
+    PG_BODY(F_SETUP, F_ISSUE, epilogue_f<S>(p, acc, m0, n0, lane, wm, wn);)
+#undef F_SETUP
+#undef F_ISSUE
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// T kernel.  GEMM rows m' = o*s + phi, K = (q, jj) with KJ = ceil(k/s) taps per phase, N = (b, u).
+// ------------------------------------------------------------------------------------------------------------
+template <int KW, int S>
+__global__ __launch_bounds__(NT, 3) void conv_t_kernel(const IgemmParams p) {
+    const int kw_ = KW ? KW : p.k, s_ = S ? S : p.s;
+    const int KJ = (kw_ + s_ - 1) / s_;
+    const int Ktot = p.Q * KJ, Ntot = p.B * p.U, Mrows = p.M * s_;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
+    const int wq = p.M * kw_;                 // weight stride between input channels q
+#define T_SETUP                                                                                       \
+    int aoff[8], jmax[8], xoff[8], ub[8];                                                             \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
+        const int mr = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);                      \
+        const int o = mr / s, phi = mr - o * s;                                                       \
+        aoff[e] = mr < Mrows ? o * kw + phi : -1;       /* W[q][o][s*jj + phi] */                      \
+        jmax[e] = kw - phi;                             /* tap exists iff s*jj < kw - phi */           \
+        const bool nv = n < Ntot;                                                                     \
+        const int b = nv ? n / p.U : 0, u = (nv ? n - b * p.U : 0) + p.u_off;                         \
+        xoff[e] = b * (int)p.x_bs + u;                  /* X[b][q][u - jj] */                          \
+        ub[e] = nv ? u : -NEVER;                        /* position u - jj must lie in [0, Lx) */      \
+    }
+#define T_ISSUE                                                                                       \
+    { const int kk = k0 + kt, q = kk / KJ, jj = kk - q * KJ, wo = q * wq + s * jj, xq = q * p.Lx - jj; \
+      const bool kok = kk < Ktot;                                                                     \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
+          dma4(rw, As + e * 256, aoff[e] + wo, kok && aoff[e] >= 0 && s * jj < jmax[e]);              \
+          dma4(rx, Bs + e * 256, xoff[e] + xq, kok && (unsigned)(ub[e] - jj) < (unsigned)p.Lx);       \
+      } }
+    PG_BODY(T_SETUP, T_ISSUE, epilogue_t<S>(p, acc, m0, n0, lane, wm, wn);)
+#undef T_SETUP
+#undef T_ISSUE
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// G kernel.  dW[m][(q,j)] = sum over kk = (b,i) of actP(P[b,m,i]) * actQ(Q[b,q,s*i+j-p]);  Q tensor is p.x.
+// ------------------------------------------------------------------------------------------------------------
+// n / d for 0 <= n < 2^24 via the float reciprocal, exact after one correction step (branch-free selects).
+__device__ __forceinline__ void divmod24(int n, int d, float inv, int& q, int& r) {
+    q = (int)((float)n * inv);
+    r = n - q * d;
+    if (r < 0) { r += d; --q; }
+    if (r >= d) { r -= d; ++q; }
+}
+
+template <int KW, int S>
+__global__ __launch_bounds__(NT, 3) void conv_g_kernel(const IgemmParams p) {
+    const int Ntot = p.Q * (KW ? KW : p.k);
+    const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    const float slopeA = act_slope(p.act_p), slopeB = act_slope(p.act_x);
+    const int pbs = (int)p.pt_bs, xbs = (int)p.x_bs;
+#define G_SETUP                                                                                       \
+    int aoff[8], xoff[8], jp[8];                                                                      \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
+        const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);                       \
+        aoff[e] = m < p.M ? m * p.LP : -1;              /* P[b][m][i] */                               \
+        const bool nv = n < Ntot;                                                                     \
+        const int q = nv ? n / kw : 0, j = nv ? n - q * kw : 0;                                       \
+        xoff[e] = q * p.Lx + j - p.p;                   /* Q[b][q][s*i + j - p] */                     \
+        jp[e] = nv ? j - p.p : -NEVER;                                                                \
+    }
+#define G_ISSUE                                                                                       \
+    { int bb, ii; divmod24(k0 + kt, p.LP, p.inv_LP, bb, ii);                                          \
+      const bool kok = bb < p.B; const int po = bb * pbs + ii, xo = bb * xbs + s * ii;                \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
+          dma4(rp, As + e * 256, aoff[e] + po, kok && aoff[e] >= 0);                                  \
+          dma4(rx, Bs + e * 256, xoff[e] + xo, kok && (unsigned)(s * ii + jp[e]) < (unsigned)p.Lx);   \
+      } }
+    PG_BODY(G_SETUP, G_ISSUE, epilogue_g<S>(p, acc, m0, n0, lane, wm, wn);)
+#undef G_SETUP
+#undef G_ISSUE
+}
+
+// ---- fixup: add the partial segments of every split tile in ascending workgroup order, then the epilogue ---------
+template <int KIND>
+__global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int G) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int tile = blockIdx.x;
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, G);
+    const int first = tile * p.nslab, last = first + p.nslab - 1;
+    const int g0 = split_owner(sp, first), g1 = split_owner(sp, last);
+    if (g0 == g1 && split_lo(sp, g0) <= first && split_lo(sp, g0 + 1) > last) return;   // computed whole by one workgroup
+    Acc acc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;
+    for (int g = g0; g <= g1; ++g) {
+        const int slot = (split_lo(sp, g) / p.nslab == tile) ? 0 : 1;     // the range's first segment, or its last
+        const float* src = p.ws + ((long)(g * 2 + slot) * 64) * NT + tid;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.c[i][j][r] += src[((i * 2 + j) * 16 + r) * NT];
+    }
+    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
+    if (KIND == 0) epilogue_f<0>(p, acc, m0, n0, lane, wm, wn);
+    else if (KIND == 1) epilogue_t<0>(p, acc, m0, n0, lane, wm, wn);
+    else epilogue_g<0>(p, acc, m0, n0, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -354,18 +443,62 @@ hipError_t launch_kind(Kind kind, const IgemmParams& p, int grid, hipStream_t st
     return hipGetLastError();
 }
 
-int launch(Kind kind, IgemmParams& p, long rows, long cols, hipStream_t st) {
+constexpr int WG_PER_CU = 3;                    // 144 VGPR+AGPR per lane -> 3 waves per SIMD; 32 KB LDS per workgroup
+constexpr int MAX_STREAMK_WG = 1024;            // bound on the persistent grid (sizes the caller's workspace)
+constexpr long WS_PER_WG = 2L * 64 * NT * 4;    // two partial tiles of 128x128 fp32 per workgroup
+
+// Number of CUs of the current device (immutable per device; cached).
+int cu_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
+// Grid policy.  tiles workgroups (one whole tile each) unless the tile count quantises badly over the CUs and the
+// caller supplied a workspace: then a persistent grid of all resident workgroup slots with the (tile, slab) space
+// split evenly (stream-K) plus the fixup launch.  mode: 0 auto, 1 force plain, 2 force stream-K (tests).
+int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mode) {
+    const int cus = cu_count();
+    long G = (long)cus * WG_PER_CU;
+    if (G > MAX_STREAMK_WG) G = MAX_STREAMK_WG;
+    if (G > tiles * (long)nslab) G = tiles * (long)nslab;
+    const bool can = p.ws && ws_bytes >= G * WS_PER_WG && tiles * (long)nslab < 0x7fffffffL;
+    if (mode == 1 || !can) return (int)tiles;
+    if (mode == 2) return (int)G;
+    const long rounds = (tiles + cus - 1) / cus;                 // whole tiles per CU, worst CU
+    const double balance = (double)tiles / (double)(rounds * cus);
+    return balance < 0.93 ? (int)G : (int)tiles;
+}
+
+int g_force_mode = 0;   // test hook, set through pg_conv_set_schedule()
+
+int launch(Kind kind, IgemmParams& p, long rows, long cols, long Ktot, long ws_bytes, hipStream_t st) {
     p.tilesM = (int)((rows + BM - 1) / BM);
     p.tilesN = (int)((cols + BN - 1) / BN);
-    const long grid = (long)p.tilesM * p.tilesN;
-    if (grid <= 0 || grid > 0x7fffffffL) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");
+    p.nslab = (int)((Ktot + BK - 1) / BK);
+    const long tiles = (long)p.tilesM * p.tilesN;
+    if (tiles <= 0 || tiles > 0x7fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");
+    const int grid = pick_grid(tiles, p.nslab, p, ws_bytes, g_force_mode);
     hipError_t e;
-    if (p.k == 32 && p.s == 2) e = launch_kind<32, 2>(kind, p, (int)grid, st);
-    else if (p.k == 8 && p.s == 1) e = launch_kind<8, 1>(kind, p, (int)grid, st);
-    else if (p.k == 8 && p.s == 2) e = launch_kind<8, 2>(kind, p, (int)grid, st);
-    else if (p.k == 4 && p.s == 2) e = launch_kind<4, 2>(kind, p, (int)grid, st);
-    else if (p.k == 5 && p.s == 2) e = launch_kind<5, 2>(kind, p, (int)grid, st);
-    else e = launch_kind<0, 0>(kind, p, (int)grid, st);
+    if (p.k == 32 && p.s == 2) e = launch_kind<32, 2>(kind, p, grid, st);
+    else if (p.k == 8 && p.s == 1) e = launch_kind<8, 1>(kind, p, grid, st);
+    else if (p.k == 8 && p.s == 2) e = launch_kind<8, 2>(kind, p, grid, st);
+    else if (p.k == 4 && p.s == 2) e = launch_kind<4, 2>(kind, p, grid, st);
+    else if (p.k == 5 && p.s == 2) e = launch_kind<5, 2>(kind, p, grid, st);
+    else e = launch_kind<0, 0>(kind, p, grid, st);
+    if (e == hipSuccess && grid != tiles) {
+        switch (kind) {
+            case KIND_F: hipLaunchKernelGGL((conv_fixup_kernel<0>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
+            case KIND_T: hipLaunchKernelGGL((conv_fixup_kernel<1>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
+            case KIND_G: hipLaunchKernelGGL((conv_fixup_kernel<2>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
+        }
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     return PG_OK;
 }
@@ -413,7 +546,8 @@ extern "C" int pg_conv1d_fwd(const pg_conv_args* a, void* stream) {
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.Ly = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
     p.act_x = a->x_act;
     if (int e = set_extents(p, p.Q, p.Lx, 0, 0)) return e;
-    return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (hipStream_t)stream);
+    p.ws = (float*)a->workspace;
+    return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (long)p.Q * p.k, a->workspace_bytes, (hipStream_t)stream);
 }
 
 // nn.ConvTranspose1d dgrad: dx[b,c,i] = sum_{o,j} w[c][o][j] dy[b,o,s*i+j-p]  -> F kernel with M = Cin, Q = Cout.
@@ -426,17 +560,18 @@ extern "C" int pg_convt1d_dgrad(const pg_conv_args* a, void* stream) {
     p.mask_mode = a->dx_ref ? a->dx_mask : 0;
     p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.Ly = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
     if (int e = set_extents(p, p.Q, p.Lx, 0, 0)) return e;
-    return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (hipStream_t)stream);
+    p.ws = (float*)a->workspace;
+    return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (long)p.Q * p.k, a->workspace_bytes, (hipStream_t)stream);
 }
 
-static int launch_t(IgemmParams& p, hipStream_t st) {
+static int launch_t(IgemmParams& p, long ws_bytes, hipStream_t st) {
     // tau = s*u + phi - p >= 0 for some phi  <=>  u >= floor(p/s) at the latest; tau <= Ly-1 => u <= (Ly-1+p)/s
     p.u_off = p.p / p.s;
     const int u_max = (p.Ly - 1 + p.p) / p.s;
     p.U = u_max - p.u_off + 1;
     if (p.U <= 0) return pg_fail(PG_ERR_SHAPE, "convT: empty output");
     if (int e = set_extents(p, p.Q, p.Lx, 0, 0)) return e;
-    return launch(KIND_T, p, (long)p.M * p.s, (long)p.B * p.U, st);
+    return launch(KIND_T, p, (long)p.M * p.s, (long)p.B * p.U, (long)p.Q * ((p.k + p.s - 1) / p.s), ws_bytes, st);
 }
 
 // nn.ConvTranspose1d forward: T kernel with M = Cout, Q = Cin.
@@ -447,7 +582,8 @@ extern "C" int pg_convt1d_fwd(const pg_conv_args* a, void* stream) {
     p.x = a->x; p.x_bs = a->x_bs; p.w = a->w; p.y = a->y; p.y_bs = a->y_bs;
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.Ly = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
     p.act_x = a->x_act;
-    return launch_t(p, (hipStream_t)stream);
+    p.ws = (float*)a->workspace;
+    return launch_t(p, a->workspace_bytes, (hipStream_t)stream);
 }
 
 // nn.Conv1d dgrad: dx[b,c,u] = sum_{o,j,t: s*t+j-p=u} w[o][c][j] dy[b,o,t]  -> T kernel with M = Cin, Q = Cout.
@@ -459,7 +595,8 @@ extern "C" int pg_conv1d_dgrad(const pg_conv_args* a, void* stream) {
     p.add = a->dx_add; p.add_bs = a->dx_add_bs; p.ref = a->dx_ref; p.ref_bs = a->dx_ref_bs;
     p.mask_mode = a->dx_ref ? a->dx_mask : 0;
     p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.Ly = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
-    return launch_t(p, (hipStream_t)stream);
+    p.ws = (float*)a->workspace;
+    return launch_t(p, a->workspace_bytes, (hipStream_t)stream);
 }
 
 // nn.Conv1d wgrad: dw[o][c][j] = sum_{b,t} dy[b,o,t] act(x)[b,c,s*t+j-p]  -> G with P = dy (M = Cout), Q = x.
@@ -471,7 +608,8 @@ extern "C" int pg_conv1d_wgrad(const pg_conv_args* a, void* stream) {
     p.x = a->x; p.x_bs = a->x_bs; p.act_x = a->x_act; p.y = a->dw;
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
     if (int e = set_extents(p, p.Q, p.Lx, p.M, p.LP)) return e;
-    return launch(KIND_G, p, p.M, (long)p.Q * p.k, (hipStream_t)stream);
+    p.ws = (float*)a->workspace;
+    return launch(KIND_G, p, p.M, (long)p.Q * p.k, (long)p.B * p.LP, a->workspace_bytes, (hipStream_t)stream);
 }
 
 // nn.ConvTranspose1d wgrad: dw[c][o][j] = sum_{b,i} act(x)[b,c,i] dy[b,o,s*i+j-p]  -> G with P = x (M = Cin), Q = dy.
@@ -483,5 +621,17 @@ extern "C" int pg_convt1d_wgrad(const pg_conv_args* a, void* stream) {
     p.x = a->dy; p.x_bs = a->dy_bs; p.act_x = PG_ACT_NONE; p.y = a->dw;
     p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
     if (int e = set_extents(p, p.Q, p.Lx, p.M, p.LP)) return e;
-    return launch(KIND_G, p, p.M, (long)p.Q * p.k, (hipStream_t)stream);
+    p.ws = (float*)a->workspace;
+    return launch(KIND_G, p, p.M, (long)p.Q * p.k, (long)p.B * p.LP, a->workspace_bytes, (hipStream_t)stream);
+}
+
+// Workspace a caller should hand to the conv entry points (pg_conv_args.workspace) so that badly quantised tile counts
+// can be balanced over all CUs (stream-K).  Without it every call falls back to one-tile-per-workgroup scheduling.
+extern "C" int64_t pg_workspace_bytes_conv(void) { return (int64_t)MAX_STREAMK_WG * WS_PER_WG; }
+
+// Test hook: 0 = automatic schedule, 1 = force one tile per workgroup, 2 = force stream-K (needs a workspace).
+extern "C" int pg_conv_set_schedule(int mode) {
+    if (mode < 0 || mode > 2) return pg_fail(PG_ERR_SHAPE, "conv_set_schedule: mode must be 0, 1 or 2");
+    g_force_mode = mode;
+    return PG_OK;
 }

@@ -26,7 +26,7 @@ class ConvArgs(C.Structure):
                 ("dx_add", C.c_void_p), ("dx_add_bs", C.c_int64),
                 ("dx_ref", C.c_void_p), ("dx_ref_bs", C.c_int64),
                 ("dx_mask", C.c_int32), ("_pad1", C.c_int32),
-                ("dw", C.c_void_p)]
+                ("dw", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class BnArgs(C.Structure):
@@ -76,6 +76,8 @@ SYMBOLS = {
     "pg_convt1d_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pg_convt1d_dgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pg_convt1d_wgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "pg_workspace_bytes_conv": (C.c_int64, []),
+    "pg_conv_set_schedule": (C.c_int, [C.c_int]),
     "pg_bn_fwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),
     "pg_bn_bwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),
     "pg_workspace_bytes_loss": (C.c_int64, [C.POINTER(LossArgs)]),

@@ -78,10 +78,29 @@ def convt_out_len(Lin, k, s, p):
     return (Lin - 1) * s - 2 * p + k
 
 
-def _conv_args(transposed, B, Cin, Cout, Lin, k, s, p):
+_conv_ws = {}
+
+
+def conv_workspace(device):
+    """One scratch buffer per device for the conv kernels' stream-K schedule (pg_workspace_bytes_conv(), 128 MiB)."""
+    ws = _conv_ws.get(device)
+    if ws is None:
+        ws = _conv_ws[device] = torch.empty(_lib.load().pg_workspace_bytes_conv(), device=device, dtype=torch.uint8)
+    return ws
+
+
+def set_conv_schedule(mode):
+    """Test hook: 0 automatic, 1 one tile per workgroup, 2 force the stream-K split."""
+    _lib.check(_lib.load().pg_conv_set_schedule(mode), "conv_set_schedule")
+
+
+def _conv_args(transposed, B, Cin, Cout, Lin, k, s, p, device=None):
     a = _lib.ConvArgs()
     a.B, a.Cin, a.Cout, a.Lin, a.k, a.stride, a.pad = B, Cin, Cout, Lin, k, s, p
     a.Lout = convt_out_len(Lin, k, s, p) if transposed else conv_out_len(Lin, k, s, p)
+    if device is not None:
+        ws = conv_workspace(device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     return a
 
 
@@ -97,7 +116,7 @@ def conv_fwd(x, w, y, stride, pad, x_act=ACT_NONE, transposed=False):
     """y = conv(act(x), w) (nn.Conv1d, model.py:77) or conv_transpose (model.py:88) -- writes into ``y``."""
     Cin, Cout, k = _geom(transposed, w)
     B, _, Lin = x.shape
-    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad)
+    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, x.device)
     if tuple(x.shape) != (B, Cin, Lin) or tuple(y.shape) != (B, Cout, a.Lout):
         raise ValueError(f"conv_fwd: shapes x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)} inconsistent (Lout {a.Lout})")
     a.x, a.x_bs = _act3(x, "x")
@@ -114,7 +133,7 @@ def conv_dgrad(dy, w, dx, stride, pad, transposed=False, add=None, ref=None, mas
     """dx = dgrad(dy, w) [+ add] [* act'(ref)] -- grad wrt the tensor the forward op read."""
     Cin, Cout, k = _geom(transposed, w)
     B, _, Lin = dx.shape
-    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad)
+    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, dx.device)
     if tuple(dy.shape) != (B, Cout, a.Lout) or tuple(dx.shape) != (B, Cin, Lin):
         raise ValueError(f"conv_dgrad: shapes dy{tuple(dy.shape)} w{tuple(w.shape)} dx{tuple(dx.shape)} inconsistent")
     a.dy, a.dy_bs = _act3(dy, "dy")
@@ -139,7 +158,7 @@ def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False):
     """dw = wgrad(act(x), dy), overwriting ``dw`` (same layout as the weight)."""
     Cin, Cout, k = _geom(transposed, dw)
     B, _, Lin = x.shape
-    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad)
+    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, x.device)
     if tuple(x.shape) != (B, Cin, Lin) or tuple(dy.shape) != (B, Cout, a.Lout):
         raise ValueError(f"conv_wgrad: shapes x{tuple(x.shape)} dy{tuple(dy.shape)} dw{tuple(dw.shape)} inconsistent")
     a.x, a.x_bs = _act3(x, "x")
