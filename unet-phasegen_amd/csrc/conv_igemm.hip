@@ -87,8 +87,8 @@ struct Acc { f32x16 c[2][2]; };
 __device__ __forceinline__ int dma_kt(int lane, int w) { return ((((lane >> 2) & 3) ^ w) << 2) | (lane & 3); }
 __device__ __forceinline__ int dma_row(int lane, int w, int e) { return 16 * e + 4 * w + (lane >> 4); }
 
-__device__ __forceinline__ void dma4(rsrc_t r, float* lds_wave_uniform, int elem_off, bool ok) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 4, ok ? elem_off * 4 : OOB, 0, 0, 0);
+__device__ __forceinline__ void dma4(rsrc_t r, float* lds_wave_uniform, int byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 4, byte_off, 0, 0, 0);
 }
 
 // One BK=16 slab: 8 x ds_read_b128 (swizzled), optional activation on the fragments, 8 k-pairs x 4 MFMA.
@@ -292,6 +292,11 @@ __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const Acc& acc,
     }
 
 constexpr int NEVER = 0x40000000;   // a "first valid tap/position" no index ever reaches: marks rows outside the tile
+// Out-of-range byte offsets that replace per-element predicates.  Descriptors span < 0x7ffffff0 bytes, so with
+//   FAR (rows outside the tile) = 0x80000000 and OOB (slabs past K) = 0x7ffffff0
+// every sum {valid row + OOB, FAR + valid k offset, FAR + OOB} stays >= 0x7ffffff0 as an unsigned 32-bit value and
+// never wraps back into range (FAR + FAR would: the two invalid cases therefore use different constants).
+constexpr int FAR = (int)0x80000000u;
 
 // ------------------------------------------------------------------------------------------------------------
 // F kernel
@@ -302,20 +307,21 @@ __global__ __launch_bounds__(NT, 3) void conv_f_kernel(const IgemmParams p) {
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
     const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
 #define F_SETUP                                                                                       \
-    int aoff[8], xoff[8], jlo[8];      /* per-row constants of this thread's 8 A rows / 8 B rows */    \
+    int aoff[8], xoff[8], jlo[8];      /* per-row constants (BYTE offsets) of this thread's 8 A rows / 8 B rows */ \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
         const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);                       \
-        aoff[e] = m < p.M ? m * Ktot + kt : -1;                                                       \
+        aoff[e] = m < p.M ? (m * Ktot + kt) * 4 : FAR;                                                \
         const bool nv = n < Ntot;                                                                     \
         const int b = nv ? n / p.Ly : 0, t = nv ? n - b * p.Ly : 0;                                   \
-        xoff[e] = b * (int)p.x_bs + s * t - p.p;        /* element offset of tap 0, channel 0 */      \
+        xoff[e] = (b * (int)p.x_bs + s * t - p.p) * 4;  /* tap 0, channel 0 */                        \
         jlo[e] = nv ? p.p - s * t : NEVER;              /* taps with 0 <= j - jlo < Lx are inside the row */ \
     }
 #define F_ISSUE                                                                                       \
-    { const int kk = k0 + kt, q = kk / kw, j = kk - q * kw, xq = q * p.Lx + j; const bool kok = kk < Ktot; \
+    { const int kk = k0 + kt, q = kk / kw; const bool kok = kk < Ktot;                                \
+      const int j = kok ? kk - q * kw : -NEVER, xq = (q * p.Lx + j) * 4, ka = kok ? k0 * 4 : OOB;     \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
-          dma4(rw, As + e * 256, aoff[e] + k0, kok && aoff[e] >= 0);                                  \
-          dma4(rx, Bs + e * 256, xoff[e] + xq, kok && (unsigned)(j - jlo[e]) < (unsigned)p.Lx);       \
+          dma4(rw, As + e * 256, aoff[e] + ka);                                                       \
+          dma4(rx, Bs + e * 256, (unsigned)(j - jlo[e]) < (unsigned)p.Lx ? xoff[e] + xq : FAR);       \
       } }
     PG_BODY(F_SETUP, F_ISSUE, epilogue_f<S>(p, acc, m0, n0, lane, wm, wn);)
 #undef F_SETUP
@@ -333,24 +339,27 @@ __global__ __launch_bounds__(NT, 3) void conv_t_kernel(const IgemmParams p) {
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
     const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
     const int wq = p.M * kw_;                 // weight stride between input channels q
+    /* every (q, jj) names a real tap when s divides k; otherwise (k5 s2) phase 1 has one tap fewer */ \
 #define T_SETUP                                                                                       \
-    int aoff[8], jmax[8], xoff[8], ub[8];                                                             \
+    int aoff[8], xoff[8], ub[8];                                                                      \
+    constexpr bool all_taps = KW != 0 && S != 0 && KW % (S ? S : 1) == 0;                             \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
         const int mr = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);                      \
         const int o = mr / s, phi = mr - o * s;                                                       \
-        aoff[e] = mr < Mrows ? o * kw + phi : -1;       /* W[q][o][s*jj + phi] */                      \
-        jmax[e] = kw - phi;                             /* tap exists iff s*jj < kw - phi */           \
+        aoff[e] = mr < Mrows ? (o * kw + phi) * 4 : FAR;     /* W[q][o][s*jj + phi] */                \
         const bool nv = n < Ntot;                                                                     \
         const int b = nv ? n / p.U : 0, u = (nv ? n - b * p.U : 0) + p.u_off;                         \
-        xoff[e] = b * (int)p.x_bs + u;                  /* X[b][q][u - jj] */                          \
+        xoff[e] = (b * (int)p.x_bs + u) * 4;            /* X[b][q][u - jj] */                          \
         ub[e] = nv ? u : -NEVER;                        /* position u - jj must lie in [0, Lx) */      \
-    }
+    }                                                                                                 \
+    int phi_of[8];                                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) { const int mr = m0 + dma_row(lane, wv, e); phi_of[e] = all_taps ? 0 : mr - (mr / s) * s; }
 #define T_ISSUE                                                                                       \
-    { const int kk = k0 + kt, q = kk / KJ, jj = kk - q * KJ, wo = q * wq + s * jj, xq = q * p.Lx - jj; \
-      const bool kok = kk < Ktot;                                                                     \
+    { const int kk = k0 + kt, q = kk / KJ; const bool kok = kk < Ktot;                                \
+      const int jj = kok ? kk - q * KJ : NEVER, wo = kok ? (q * wq + s * jj) * 4 : OOB, xq = (q * p.Lx - jj) * 4; \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
-          dma4(rw, As + e * 256, aoff[e] + wo, kok && aoff[e] >= 0 && s * jj < jmax[e]);              \
-          dma4(rx, Bs + e * 256, xoff[e] + xq, kok && (unsigned)(ub[e] - jj) < (unsigned)p.Lx);       \
+          dma4(rw, As + e * 256, (all_taps || s * jj + phi_of[e] < kw) ? aoff[e] + wo : FAR);         \
+          dma4(rx, Bs + e * 256, (unsigned)(ub[e] - jj) < (unsigned)p.Lx ? xoff[e] + xq : FAR);       \
       } }
     PG_BODY(T_SETUP, T_ISSUE, epilogue_t<S>(p, acc, m0, n0, lane, wm, wn);)
 #undef T_SETUP
@@ -378,18 +387,19 @@ __global__ __launch_bounds__(NT, 3) void conv_g_kernel(const IgemmParams p) {
     int aoff[8], xoff[8], jp[8];                                                                      \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
         const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);                       \
-        aoff[e] = m < p.M ? m * p.LP : -1;              /* P[b][m][i] */                               \
+        aoff[e] = m < p.M ? m * p.LP * 4 : FAR;         /* P[b][m][i] */                               \
         const bool nv = n < Ntot;                                                                     \
         const int q = nv ? n / kw : 0, j = nv ? n - q * kw : 0;                                       \
-        xoff[e] = q * p.Lx + j - p.p;                   /* Q[b][q][s*i + j - p] */                     \
+        xoff[e] = (q * p.Lx + j - p.p) * 4;             /* Q[b][q][s*i + j - p] */                     \
         jp[e] = nv ? j - p.p : -NEVER;                                                                \
     }
 #define G_ISSUE                                                                                       \
     { int bb, ii; divmod24(k0 + kt, p.LP, p.inv_LP, bb, ii);                                          \
-      const bool kok = bb < p.B; const int po = bb * pbs + ii, xo = bb * xbs + s * ii;                \
+      const bool kok = bb < p.B; const int po = kok ? (bb * pbs + ii) * 4 : OOB, xo = (bb * xbs + s * ii) * 4; \
+      const int si = kok ? s * ii : -NEVER;       /* with jp = -NEVER the sum is still far below 0 */                                                            \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
-          dma4(rp, As + e * 256, aoff[e] + po, kok && aoff[e] >= 0);                                  \
-          dma4(rx, Bs + e * 256, xoff[e] + xo, kok && (unsigned)(s * ii + jp[e]) < (unsigned)p.Lx);   \
+          dma4(rp, As + e * 256, aoff[e] + po);                                                       \
+          dma4(rx, Bs + e * 256, (unsigned)(si + jp[e]) < (unsigned)p.Lx ? xoff[e] + xo : FAR);       \
       } }
     PG_BODY(G_SETUP, G_ISSUE, epilogue_g<S>(p, acc, m0, n0, lane, wm, wn);)
 #undef G_SETUP
