@@ -17,6 +17,7 @@ ap.add_argument("what", nargs="*", default=["U0.fwd", "U0.dgrad", "U0.wgrad", "D
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--lib", default=None)
+ap.add_argument("--stamps", action="store_true")
 a = ap.parse_args()
 if a.lib:
     from phasegen import _lib
@@ -42,6 +43,14 @@ for item in a.what:
           "dgrad": lambda: ops.conv_dgrad(dy, w, dx, s, p, transposed=tr, ref=x, mask=2),
           "wgrad": lambda: ops.conv_wgrad(x, dy, dw, s, p, x_act=2, transposed=tr)}[ps]
     fn(); torch.cuda.synchronize()
+    if a.stamps:
+        ops.set_conv_schedule(1)
+        ws = ops.conv_workspace(x.device); ws[:64].zero_(); fn(); torch.cuda.synchronize()
+        c = ws[:32].view(torch.int64).cpu().tolist()
+        nsl = max(c[3], 1)
+        print(f"{item}: per wave-slab cycles  issue {c[0]/nsl:.0f}  read+mfma {c[1]/nsl:.0f}  barrier {c[2]/nsl:.0f}  total {(c[0]+c[1]+c[2])/nsl:.0f}  (wave-slabs {nsl})")
+        ops.set_conv_schedule(0)
+        continue
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.reps):

@@ -25,8 +25,11 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, NT = 256;
-constexpr int TILE = BM * BK;             // floats per operand tile (8 KB); 2 operands x 2 buffers = 32 KB LDS
+constexpr int WMB = 4;                    // 32-row MFMA blocks per wave along M: wave tile (32*WMB) x 64
+constexpr int BM = 64 * WMB, BN = 128, BK = 16, NT = 256;   // workgroup tile 256 x 128, waves 2 (M) x 2 (N)
+constexpr int TILE_A = BM * BK, TILE_B = BN * BK;   // floats per operand tile (16 KB + 8 KB)
+constexpr int STAGE = TILE_A + TILE_B;    // one LDS stage; two stages = 48 KB
+constexpr int AE = BM / 16;               // dword gather pieces per thread and slab for the A tile (B tile: 8)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -75,7 +78,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-struct Acc { f32x16 c[2][2]; };
+struct Acc { f32x16 c[WMB][2]; };
 
 // ---- LDS tile image --------------------------------------------------------------------------------------------
 // One operand tile = 128 rows x 16 k, UNPADDED (64-B rows), 16-B chunks XOR-swizzled by (row>>2)&3: element (r,k) sits
@@ -87,27 +90,42 @@ struct Acc { f32x16 c[2][2]; };
 __device__ __forceinline__ int dma_kt(int lane, int w) { return ((((lane >> 2) & 3) ^ w) << 2) | (lane & 3); }
 __device__ __forceinline__ int dma_row(int lane, int w, int e) { return 16 * e + 4 * w + (lane >> 4); }
 
+// 16 bytes per lane: one wave instruction fills 16 rows x 64 B.  Lane L lands on 16-B chunk (4e+w)*64 + L of the tile
+// image: row (4e+w)*16 + (L>>2), physical chunk L&3, i.e. logical chunk (L&3) ^ ((L>>4)&3) of that row.
+__device__ __forceinline__ int dma16_row(int lane, int w, int e) { return (4 * e + w) * 16 + (lane >> 2); }
+__device__ __forceinline__ int dma16_kc(int lane) { return ((lane & 3) ^ ((lane >> 4) & 3)) << 2; }
+#ifndef PG_ABL
+#define PG_ABL 0
+#endif
+#if PG_ABL == 4     /* dev ablation: identical instruction stream, every gather address folded into a 1 KB window */
+#define PG_ADDR(x) ((x) & 0x3f0)
+#else
+#define PG_ADDR(x) (x)
+#endif
+__device__ __forceinline__ void dma16(rsrc_t r, float* lds_wave_uniform, int byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 16, PG_ADDR(byte_off), 0, 0, 0);
+}
 __device__ __forceinline__ void dma4(rsrc_t r, float* lds_wave_uniform, int byte_off) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 4, byte_off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 4, PG_ADDR(byte_off), 0, 0, 0);
 }
 
-// One BK=16 slab: 8 x ds_read_b128 (swizzled), optional activation on the fragments, 8 k-pairs x 4 MFMA.
+// One BK=16 slab: (2*WMB + 4) x ds_read_b128 (swizzled), optional activation on the fragments, 8 k-pairs x 2*WMB MFMA.
 __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs,
                                          int lane, int wm, int wn, float slopeA, float slopeB, Acc& acc) {
     const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
-    const float* ap = As + (wm * 64 + r) * BK;
+    const float* ap = As + (wm * (WMB * 32) + r) * BK;
     const float* bp = Bs + (wn * 64 + r) * BK;
-    f32x4 a[2][2], b[2][2];
+    f32x4 a[WMB][2], b[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
-            b[i][c] = *reinterpret_cast<const f32x4*>(bp + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
-        }
+        for (int i = 0; i < WMB; ++i) a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b[i][c] = *reinterpret_cast<const f32x4*>(bp + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+    }
     if (slopeA != 1.0f) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WMB; ++i)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -122,14 +140,12 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const flo
                 for (int v = 0; v < 4; ++v) b[i][c][v] = act_apply(b[i][c][v], slopeB);
     }
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        const float a0 = a[0][kk >> 2][kk & 3], a1 = a[1][kk >> 2][kk & 3];
-        const float b0 = b[0][kk >> 2][kk & 3], b1 = b[1][kk >> 2][kk & 3];
-        acc.c[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.c[0][0], 0, 0, 0);
-        acc.c[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.c[0][1], 0, 0, 0);
-        acc.c[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.c[1][0], 0, 0, 0);
-        acc.c[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.c[1][1], 0, 0, 0);
-    }
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int i = 0; i < WMB; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk >> 2][kk & 3], acc.c[i][j], 0, 0, 0);
 }
 
 // Fused dgrad epilogue: v = (acc + add) * act'(ref).  A missing addend / mask source is an EMPTY descriptor (every
@@ -167,10 +183,11 @@ __device__ __host__ __forceinline__ int split_owner(const Split& sp, int x) {
     return x < big ? x / (sp.q + 1) : sp.r + (x - big) / sp.q;
 }
 
+constexpr int ACC_REGS = WMB * 2 * 16;    // accumulator registers per thread = floats per thread of a partial tile
 __device__ __forceinline__ void store_partial(float* ws, int g, int slot, const Acc& acc, int tid) {
-    float* dst = ws + ((long)(g * 2 + slot) * 64) * NT + tid;
+    float* dst = ws + ((long)(g * 2 + slot) * ACC_REGS) * NT + tid;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WMB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -190,10 +207,10 @@ __device__ __forceinline__ void epilogue_f(const IgemmParams& p, const Acc& acc,
         const int b = n / p.Ly, t = n - b * p.Ly;
         float* yb = p.y + (long)b * p.y_bs;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WMB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * (WMB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     const int off = m * p.Ly + t;
                     float v = acc.c[i][j][r];
@@ -216,10 +233,10 @@ __device__ __forceinline__ void epilogue_t(const IgemmParams& p, const Acc& acc,
         const int b = n / p.U, u = n - b * p.U + p.u_off;
         float* yb = p.y + (long)b * p.y_bs;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WMB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int mr = m0 + wm * (WMB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int o = mr / s, phi = mr - o * s, tau = s * u + phi - p.p;
                 if (mr < Mrows && tau >= 0 && tau < p.Ly) {
                     const int off = o * p.Ly + tau;
@@ -239,10 +256,10 @@ __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const Acc& acc,
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
         if (n >= Ntot) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WMB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * (WMB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) p.y[(long)m * Ntot + n] = acc.c[i][j][r];
             }
     }
@@ -254,12 +271,23 @@ __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const Acc& acc,
 // the slab's 32 MFMAs (phase order pinned with sched_barrier: hipcc otherwise hoists the register-only MFMAs above the
 // gather issue), so gather latency is covered by matrix work.  buf^1 is refilled while buf is read: its previous
 // readers all passed the barrier that ended the last iteration.
+#if PG_ABL == 7   /* dev-only: s_memtime stamps around the three phases of a slab; sums go to p.ws (u64 x 4) */
+#define PG_STAMP(i) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); if (i) st_sum[i - 1] += t_ - st_prev; st_prev = t_; }
+#define PG_STAMP_FLUSH if (lane == 0) { for (int i_ = 0; i_ < 3; ++i_) atomicAdd((unsigned long long*)p.ws + i_, st_sum[i_]); \
+                                        atomicAdd((unsigned long long*)p.ws + 3, (unsigned long long)(se - sb)); }
+#define PG_STAMP_DECL unsigned long long st_sum[3] = {0, 0, 0}, st_prev = 0;
+#else
+#define PG_STAMP(i)
+#define PG_STAMP_FLUSH
+#define PG_STAMP_DECL
+#endif
 #define PG_BODY(SETUP, ISSUE, EPILOGUE)                                                             \
     const int tid = threadIdx.x, lane = tid & 63;                                                   \
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;             \
     const int kw = KW ? KW : p.k, s = S ? S : p.s;                                                  \
     const int kt = dma_kt(lane, wv);                                                                \
-    __shared__ __attribute__((aligned(16))) float lds[4 * TILE];                                    \
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];                                   \
     const int g = xcd_remap(blockIdx.x, gridDim.x);                                                 \
     const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);                           \
     int pos = split_lo(sp, g);                                                                      \
@@ -270,21 +298,27 @@ __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const Acc& acc,
         const int se = min(p.nslab, sb + (pos_end - pos));                                          \
         const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;                         \
         SETUP                                                                                       \
+        PG_STAMP_DECL                                                                               \
         Acc acc;                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+        _Pragma("unroll") for (int i = 0; i < WMB; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;                    \
-        { float* const As = lds + wv * 64; float* const Bs = As + TILE; const int k0 = sb * BK; ISSUE } \
+        { float* const As = lds + wv * 64; float* const Bs = As + TILE_A; const int k0 = sb * BK; ISSUE } \
         __syncthreads();                                                                            \
         for (int sl = sb; sl < se; ++sl) {                                                          \
             const int cur = (sl - sb) & 1;                                                          \
-            { float* const As = lds + (cur ^ 1) * 2 * TILE + wv * 64; float* const Bs = As + TILE;  \
+            PG_STAMP(0)                                                                             \
+            { float* const As = lds + (cur ^ 1) * STAGE + wv * 64; float* const Bs = As + TILE_A;   \
               const int k0 = (sl + 1) * BK;    /* past-the-end slab gathers only zeros */           \
               ISSUE }                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                      \
-            mma_slab(lds + cur * 2 * TILE, lds + cur * 2 * TILE + TILE, lane, wm, wn, slopeA, slopeB, acc); \
+            PG_STAMP(1)                                                                             \
+            mma_slab(lds + cur * STAGE, lds + cur * STAGE + TILE_A, lane, wm, wn, slopeA, slopeB, acc); \
             __builtin_amdgcn_sched_barrier(0);                                                      \
+            PG_STAMP(2)                                                                             \
             __syncthreads();                                                                        \
+            PG_STAMP(3)                                                                             \
         }                                                                                           \
+        PG_STAMP_FLUSH                                                                                           \
         if (sb == 0 && se == p.nslab) { EPILOGUE }                                                  \
         else store_partial(p.ws, g, slot, acc, tid);                                                \
         pos += se - sb;                                                                             \
@@ -302,27 +336,40 @@ constexpr int FAR = (int)0x80000000u;
 // F kernel
 // ------------------------------------------------------------------------------------------------------------
 template <int KW, int S>
-__global__ __launch_bounds__(NT, 3) void conv_f_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(NT, 2) void conv_f_kernel(const IgemmParams p) {
     const int Ktot = p.Q * (KW ? KW : p.k), Ntot = p.B * p.Ly;
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
     const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
 #define F_SETUP                                                                                       \
-    int aoff[8], xoff[8], jlo[8];      /* per-row constants (BYTE offsets) of this thread's 8 A rows / 8 B rows */ \
+    int aoff[AE], xoff[8], jlo[8];     /* per-row constants (BYTE offsets) of this thread's A rows / 8 B rows */ \
+    _Pragma("unroll") for (int e = 0; e < AE; ++e) {                                                  \
+        const int m = m0 + dma_row(lane, wv, e);                                                      \
+        aoff[e] = (!p.a_vec && m < p.M) ? (m * Ktot + kt) * 4 : FAR;                                  \
+    }                                                                                                 \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
-        const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);                       \
-        aoff[e] = m < p.M ? (m * Ktot + kt) * 4 : FAR;                                                \
+        const int n = n0 + dma_row(lane, wv, e);                                                      \
         const bool nv = n < Ntot;                                                                     \
         const int b = nv ? n / p.Ly : 0, t = nv ? n - b * p.Ly : 0;                                   \
         xoff[e] = (b * (int)p.x_bs + s * t - p.p) * 4;  /* tap 0, channel 0 */                        \
         jlo[e] = nv ? p.p - s * t : NEVER;              /* taps with 0 <= j - jlo < Lx are inside the row */ \
+    }                                                                                                 \
+    int avoff[BM / 64];                /* dense weight rows as 16-B pieces (BM/64 per slab instead of BM/16) */ \
+    _Pragma("unroll") for (int e = 0; e < BM / 64; ++e) {                                             \
+        const int m = m0 + dma16_row(lane, wv, e);                                                    \
+        avoff[e] = m < p.M ? (m * Ktot + dma16_kc(lane)) * 4 : FAR;                                   \
     }
 #define F_ISSUE                                                                                       \
     { const int kk = k0 + kt, q = kk / kw; const bool kok = kk < Ktot;                                \
       const int j = kok ? kk - q * kw : -NEVER, xq = (q * p.Lx + j) * 4, ka = kok ? k0 * 4 : OOB;     \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
-          dma4(rw, As + e * 256, aoff[e] + ka);                                                       \
+      if (p.a_vec) {                                                                                  \
+          const int kv = (k0 + dma16_kc(lane) < Ktot) ? k0 * 4 : OOB;                                 \
+          _Pragma("unroll") for (int e = 0; e < BM / 64; ++e) dma16(rw, As + wv * 192 + e * 1024, avoff[e] + kv); \
+      } else {                                                                                        \
+          _Pragma("unroll") for (int e = 0; e < AE; ++e) dma4(rw, As + e * 256, aoff[e] + ka);        \
+      }                                                                                               \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                   \
           dma4(rx, Bs + e * 256, (unsigned)(j - jlo[e]) < (unsigned)p.Lx ? xoff[e] + xq : FAR);       \
-      } }
+    }
     PG_BODY(F_SETUP, F_ISSUE, epilogue_f<S>(p, acc, m0, n0, lane, wm, wn);)
 #undef F_SETUP
 #undef F_ISSUE
@@ -332,7 +379,7 @@ __global__ __launch_bounds__(NT, 3) void conv_f_kernel(const IgemmParams p) {
 // T kernel.  GEMM rows m' = o*s + phi, K = (q, jj) with KJ = ceil(k/s) taps per phase, N = (b, u).
 // ------------------------------------------------------------------------------------------------------------
 template <int KW, int S>
-__global__ __launch_bounds__(NT, 3) void conv_t_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(NT, 2) void conv_t_kernel(const IgemmParams p) {
     const int kw_ = KW ? KW : p.k, s_ = S ? S : p.s;
     const int KJ = (kw_ + s_ - 1) / s_;
     const int Ktot = p.Q * KJ, Ntot = p.B * p.U, Mrows = p.M * s_;
@@ -341,26 +388,30 @@ __global__ __launch_bounds__(NT, 3) void conv_t_kernel(const IgemmParams p) {
     const int wq = p.M * kw_;                 // weight stride between input channels q
     /* every (q, jj) names a real tap when s divides k; otherwise (k5 s2) phase 1 has one tap fewer */ \
 #define T_SETUP                                                                                       \
-    int aoff[8], xoff[8], ub[8];                                                                      \
+    int aoff[AE], xoff[8], ub[8];                                                                     \
     constexpr bool all_taps = KW != 0 && S != 0 && KW % (S ? S : 1) == 0;                             \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
-        const int mr = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);                      \
+    _Pragma("unroll") for (int e = 0; e < AE; ++e) {                                                  \
+        const int mr = m0 + dma_row(lane, wv, e);                                                     \
         const int o = mr / s, phi = mr - o * s;                                                       \
         aoff[e] = mr < Mrows ? (o * kw + phi) * 4 : FAR;     /* W[q][o][s*jj + phi] */                \
+    }                                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
+        const int n = n0 + dma_row(lane, wv, e);                                                      \
         const bool nv = n < Ntot;                                                                     \
         const int b = nv ? n / p.U : 0, u = (nv ? n - b * p.U : 0) + p.u_off;                         \
         xoff[e] = (b * (int)p.x_bs + u) * 4;            /* X[b][q][u - jj] */                          \
         ub[e] = nv ? u : -NEVER;                        /* position u - jj must lie in [0, Lx) */      \
     }                                                                                                 \
-    int phi_of[8];                                                                                    \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) { const int mr = m0 + dma_row(lane, wv, e); phi_of[e] = all_taps ? 0 : mr - (mr / s) * s; }
+    int phi_of[AE];                                                                                   \
+    _Pragma("unroll") for (int e = 0; e < AE; ++e) { const int mr = m0 + dma_row(lane, wv, e); phi_of[e] = all_taps ? 0 : mr - (mr / s) * s; }
 #define T_ISSUE                                                                                       \
     { const int kk = k0 + kt, q = kk / KJ; const bool kok = kk < Ktot;                                \
       const int jj = kok ? kk - q * KJ : NEVER, wo = kok ? (q * wq + s * jj) * 4 : OOB, xq = (q * p.Lx - jj) * 4; \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
+      _Pragma("unroll") for (int e = 0; e < AE; ++e)                                                  \
           dma4(rw, As + e * 256, (all_taps || s * jj + phi_of[e] < kw) ? aoff[e] + wo : FAR);         \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                   \
           dma4(rx, Bs + e * 256, (unsigned)(ub[e] - jj) < (unsigned)p.Lx ? xoff[e] + xq : FAR);       \
-      } }
+    }
     PG_BODY(T_SETUP, T_ISSUE, epilogue_t<S>(p, acc, m0, n0, lane, wm, wn);)
 #undef T_SETUP
 #undef T_ISSUE
@@ -378,16 +429,19 @@ __device__ __forceinline__ void divmod24(int n, int d, float inv, int& q, int& r
 }
 
 template <int KW, int S>
-__global__ __launch_bounds__(NT, 3) void conv_g_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(NT, 2) void conv_g_kernel(const IgemmParams p) {
     const int Ntot = p.Q * (KW ? KW : p.k);
     const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
     const float slopeA = act_slope(p.act_p), slopeB = act_slope(p.act_x);
     const int pbs = (int)p.pt_bs, xbs = (int)p.x_bs;
 #define G_SETUP                                                                                       \
-    int aoff[8], xoff[8], jp[8];                                                                      \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
-        const int m = m0 + dma_row(lane, wv, e), n = n0 + dma_row(lane, wv, e);                       \
+    int aoff[AE], xoff[8], jp[8];                                                                     \
+    _Pragma("unroll") for (int e = 0; e < AE; ++e) {                                                  \
+        const int m = m0 + dma_row(lane, wv, e);                                                      \
         aoff[e] = m < p.M ? m * p.LP * 4 : FAR;         /* P[b][m][i] */                               \
+    }                                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
+        const int n = n0 + dma_row(lane, wv, e);                                                      \
         const bool nv = n < Ntot;                                                                     \
         const int q = nv ? n / kw : 0, j = nv ? n - q * kw : 0;                                       \
         xoff[e] = (q * p.Lx + j - p.p) * 4;             /* Q[b][q][s*i + j - p] */                     \
@@ -397,10 +451,10 @@ __global__ __launch_bounds__(NT, 3) void conv_g_kernel(const IgemmParams p) {
     { int bb, ii; divmod24(k0 + kt, p.LP, p.inv_LP, bb, ii);                                          \
       const bool kok = bb < p.B; const int po = kok ? (bb * pbs + ii) * 4 : OOB, xo = (bb * xbs + s * ii) * 4; \
       const int si = kok ? s * ii : -NEVER;       /* with jp = -NEVER the sum is still far below 0 */                                                            \
-      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                 \
-          dma4(rp, As + e * 256, aoff[e] + po);                                                       \
+      _Pragma("unroll") for (int e = 0; e < AE; ++e) dma4(rp, As + e * 256, aoff[e] + po);            \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                   \
           dma4(rx, Bs + e * 256, (unsigned)(si + jp[e]) < (unsigned)p.Lx ? xoff[e] + xo : FAR);       \
-      } }
+    }
     PG_BODY(G_SETUP, G_ISSUE, epilogue_g<S>(p, acc, m0, n0, lane, wm, wn);)
 #undef G_SETUP
 #undef G_ISSUE
@@ -417,16 +471,16 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
     if (g0 == g1 && split_lo(sp, g0) <= first && split_lo(sp, g0 + 1) > last) return;   // computed whole by one workgroup
     Acc acc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WMB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;
     for (int g = g0; g <= g1; ++g) {
         const int slot = (split_lo(sp, g) / p.nslab == tile) ? 0 : 1;     // the range's first segment, or its last
-        const float* src = p.ws + ((long)(g * 2 + slot) * 64) * NT + tid;
+        const float* src = p.ws + ((long)(g * 2 + slot) * ACC_REGS) * NT + tid;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WMB; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -453,9 +507,9 @@ hipError_t launch_kind(Kind kind, const IgemmParams& p, int grid, hipStream_t st
     return hipGetLastError();
 }
 
-constexpr int WG_PER_CU = 3;                    // 144 VGPR+AGPR per lane -> 3 waves per SIMD; 32 KB LDS per workgroup
-constexpr int MAX_STREAMK_WG = 1024;            // bound on the persistent grid (sizes the caller's workspace)
-constexpr long WS_PER_WG = 2L * 64 * NT * 4;    // two partial tiles of 128x128 fp32 per workgroup
+constexpr int WG_PER_CU = 2;                    // <= 256 VGPR+AGPR per lane -> 2 waves per SIMD; 48 KB LDS per workgroup
+constexpr int MAX_STREAMK_WG = 768;             // bound on the persistent grid (sizes the caller's workspace)
+constexpr long WS_PER_WG = 2L * ACC_REGS * NT * 4;   // two partial tiles of 256x128 fp32 per workgroup
 
 // Number of CUs of the current device (immutable per device; cached).
 int cu_count() {
