@@ -78,7 +78,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-struct Acc { f32x16 c[WMB][2]; };
+template <int MB, int NB> struct AccT { f32x16 c[MB][NB]; };   // MB x NB blocks of 32x32 per wave
+using Acc = AccT<WMB, 2>;       // im2col kernels: wave tile 128 x 64
+using AccR = AccT<2, 4>;        // raw-window kernels: wave tile 64 x 128
 
 // ---- LDS tile image --------------------------------------------------------------------------------------------
 // One operand tile = 128 rows x 16 k, UNPADDED (64-B rows), 16-B chunks XOR-swizzled by (row>>2)&3: element (r,k) sits
@@ -183,34 +185,37 @@ __device__ __host__ __forceinline__ int split_owner(const Split& sp, int x) {
     return x < big ? x / (sp.q + 1) : sp.r + (x - big) / sp.q;
 }
 
-constexpr int ACC_REGS = WMB * 2 * 16;    // accumulator registers per thread = floats per thread of a partial tile
-__device__ __forceinline__ void store_partial(float* ws, int g, int slot, const Acc& acc, int tid) {
+constexpr int ACC_REGS = 128;             // accumulator registers per thread in both tile configurations (8 blocks x 16)
+template <int MB, int NB>
+__device__ __forceinline__ void store_partial(float* ws, int g, int slot, const AccT<MB, NB>& acc, int tid) {
+    static_assert(MB * NB * 16 == ACC_REGS, "partial-tile slots are sized for 8 blocks per wave");
     float* dst = ws + ((long)(g * 2 + slot) * ACC_REGS) * NT + tid;
 #pragma unroll
-    for (int i = 0; i < WMB; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[((i * 2 + j) * 16 + r) * NT] = acc.c[i][j][r];
+            for (int r = 0; r < 16; ++r) dst[((i * NB + j) * 16 + r) * NT] = acc.c[i][j][r];
 }
 
 // ---- epilogues (shared by the GEMM kernels and the fixup kernels) -------------------------------------------------
-// acc reg r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
-template <int S>
-__device__ __forceinline__ void epilogue_f(const IgemmParams& p, const Acc& acc, int m0, int n0, int lane, int wm, int wn) {
+// acc reg r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31; wave (wm, wn) owns rows
+// wm*32*MB + ..., cols wn*32*NB + ...
+template <int S, int MB, int NB>
+__device__ __forceinline__ void epilogue_f(const IgemmParams& p, const AccT<MB, NB>& acc, int m0, int n0, int lane, int wm, int wn) {
     const int Ntot = p.B * p.Ly;
     const Epi ep(p, (unsigned)((long)p.M * p.Ly * 4));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * (NB * 32) + j * 32 + (lane & 31);
         if (n >= Ntot) continue;
         const int b = n / p.Ly, t = n - b * p.Ly;
         float* yb = p.y + (long)b * p.y_bs;
 #pragma unroll
-        for (int i = 0; i < WMB; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (WMB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * (MB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) {
                     const int off = m * p.Ly + t;
                     float v = acc.c[i][j][r];
@@ -221,22 +226,22 @@ __device__ __forceinline__ void epilogue_f(const IgemmParams& p, const Acc& acc,
     }
 }
 
-template <int S>
-__device__ __forceinline__ void epilogue_t(const IgemmParams& p, const Acc& acc, int m0, int n0, int lane, int wm, int wn) {
+template <int S, int MB, int NB>
+__device__ __forceinline__ void epilogue_t(const IgemmParams& p, const AccT<MB, NB>& acc, int m0, int n0, int lane, int wm, int wn) {
     const int s = S ? S : p.s;
     const int Ntot = p.B * p.U, Mrows = p.M * s;
     const Epi ep(p, (unsigned)((long)p.M * p.Ly * 4));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * (NB * 32) + j * 32 + (lane & 31);
         if (n >= Ntot) continue;
         const int b = n / p.U, u = n - b * p.U + p.u_off;
         float* yb = p.y + (long)b * p.y_bs;
 #pragma unroll
-        for (int i = 0; i < WMB; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int mr = m0 + wm * (WMB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int mr = m0 + wm * (MB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int o = mr / s, phi = mr - o * s, tau = s * u + phi - p.p;
                 if (mr < Mrows && tau >= 0 && tau < p.Ly) {
                     const int off = o * p.Ly + tau;
@@ -248,18 +253,18 @@ __device__ __forceinline__ void epilogue_t(const IgemmParams& p, const Acc& acc,
     }
 }
 
-template <int S>
-__device__ __forceinline__ void epilogue_g(const IgemmParams& p, const Acc& acc, int m0, int n0, int lane, int wm, int wn) {
+template <int S, int MB, int NB>
+__device__ __forceinline__ void epilogue_g(const IgemmParams& p, const AccT<MB, NB>& acc, int m0, int n0, int lane, int wm, int wn) {
     const int Ntot = p.Q * p.k;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * (NB * 32) + j * 32 + (lane & 31);
         if (n >= Ntot) continue;
 #pragma unroll
-        for (int i = 0; i < WMB; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (WMB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * (MB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) p.y[(long)m * Ntot + n] = acc.c[i][j][r];
             }
     }
@@ -282,7 +287,7 @@ __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const Acc& acc,
 #define PG_STAMP_FLUSH
 #define PG_STAMP_DECL
 #endif
-#define PG_BODY(SETUP, ISSUE, EPILOGUE)                                                             \
+#define PG_BODY(SETUP, ISSUE, ...)   /* variadic tail = the epilogue call (its template arguments contain commas) */                                                             \
     const int tid = threadIdx.x, lane = tid & 63;                                                   \
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;             \
     const int kw = KW ? KW : p.k, s = S ? S : p.s;                                                  \
@@ -319,7 +324,7 @@ __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const Acc& acc,
             PG_STAMP(3)                                                                             \
         }                                                                                           \
         PG_STAMP_FLUSH                                                                                           \
-        if (sb == 0 && se == p.nslab) { EPILOGUE }                                                  \
+        if (sb == 0 && se == p.nslab) { __VA_ARGS__ }                                               \
         else store_partial(p.ws, g, slot, acc, tid);                                                \
         pos += se - sb;                                                                             \
         slot = 1;                                                                                   \
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(NT, 2) void conv_f_kernel(const IgemmParams p) {
       _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                   \
           dma4(rx, Bs + e * 256, (unsigned)(j - jlo[e]) < (unsigned)p.Lx ? xoff[e] + xq : FAR);       \
     }
-    PG_BODY(F_SETUP, F_ISSUE, epilogue_f<S>(p, acc, m0, n0, lane, wm, wn);)
+    PG_BODY(F_SETUP, F_ISSUE, epilogue_f<S, WMB, 2>(p, acc, m0, n0, lane, wm, wn);)
 #undef F_SETUP
 #undef F_ISSUE
 }
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(NT, 2) void conv_t_kernel(const IgemmParams p) {
       _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                   \
           dma4(rx, Bs + e * 256, (unsigned)(ub[e] - jj) < (unsigned)p.Lx ? xoff[e] + xq : FAR);       \
     }
-    PG_BODY(T_SETUP, T_ISSUE, epilogue_t<S>(p, acc, m0, n0, lane, wm, wn);)
+    PG_BODY(T_SETUP, T_ISSUE, epilogue_t<S, WMB, 2>(p, acc, m0, n0, lane, wm, wn);)
 #undef T_SETUP
 #undef T_ISSUE
 }
@@ -455,13 +460,211 @@ __global__ __launch_bounds__(NT, 2) void conv_g_kernel(const IgemmParams p) {
       _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                   \
           dma4(rx, Bs + e * 256, (unsigned)(si + jp[e]) < (unsigned)p.Lx ? xoff[e] + xo : FAR);       \
     }
-    PG_BODY(G_SETUP, G_ISSUE, epilogue_g<S>(p, acc, m0, n0, lane, wm, wn);)
+    PG_BODY(G_SETUP, G_ISSUE, epilogue_g<S, WMB, 2>(p, acc, m0, n0, lane, wm, wn);)
 #undef G_SETUP
 #undef G_ISSUE
 }
 
+// ================================================================================================================
+// Raw-window variants of the F and T kernels: workgroup tile 128 (M) x 256 (N), wave tile 64 x 128.
+//
+// The stamps showed that what limits the im2col kernels is the number of bytes moved global -> LDS per MFMA (LDS-DMA
+// sustains only a few B/clk per CU).  An im2col tile holds every activation element k/s times.  Here the activation
+// operand is staged RAW: for each channel of a slab one contiguous window of the input row (every element once,
+// zero-filled outside [0, Lx)), and the im2col overlap is resolved when the MFMA fragments are read: column c of the
+// tile reads taps at window offset vcol(c) + tap (F) or vcol(c) - tap (T), vcol(c) = s'*c + 16*seg(c), where seg(c)
+// counts the sample boundaries between column 0 and c (a 16-float gap per boundary keeps windows of different samples
+// apart).  The tile is made wide on the activation side, where bytes are now cheap: per slab 8 KB of weights plus ~1-2 KB
+// of activations feed 128x256x16 MACs -- 60 % fewer global->LDS bytes per MFMA than the 256x128 im2col tiling.
+// Supported when the taps per channel in K order (F: k, T: k/s) are 4, 8, 16 or 32 and the windows fit RS floats;
+// everything else (k = 5, generic) stays on the im2col kernels.
+// ================================================================================================================
+constexpr int RBM = 128, RBN = 256;       // raw-window workgroup tile
+constexpr int RS = 768;                   // floats reserved per channel window
+constexpr int RG = 16;                    // gap between the windows of consecutive samples inside a tile
+constexpr int RTILE_A = RBM * BK;         // weight tile, same swizzled image as above (8 KB)
+
+// ds_read_b32-based B fragments: lane (column block jb, column r, half h) needs k = 8h .. 8h+7 of the slab, i.e.
+// (channel qi, tap tau) = divmod(8h + i, TJ); the element lives at  qi*RS + bbase[jb] +/- tau.
+template <int TJ, bool DESC>
+__device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
+                                             const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
+    const float* ap = As + (wm * 64 + r) * BK;
+    f32x4 a[2][2];
+    float b[4][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+    // lane part of the index: TJ == 16 -> one channel, taps 8h + i;  TJ <= 8 -> channels (8/TJ)*h + i/TJ, taps i % TJ
+    const int lanepart = (TJ == 16) ? (DESC ? -8 * h : 8 * h) : (8 / TJ) * h * RS;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        const float* bp = Bw + bbase[jb] + lanepart;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int qoff = (TJ == 16) ? 0 : (i / TJ) * RS, tau = (TJ == 16) ? i : (i % TJ);
+            b[jb][i] = bp[qoff + (DESC ? -tau : tau)];
+        }
+    }
+    if (slopeA != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a[i][c][v] = act_apply(a[i][c][v], slopeA);
+    }
+    if (slopeB != 1.0f) {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b[jb][i] = act_apply(b[jb][i], slopeB);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk], acc.c[i][j], 0, 0, 0);
+}
+
+// TKIND false: F (conv fwd / convT dgrad, taps ascend with stride s between columns)
+// TKIND true : T (convT fwd / conv dgrad in gather form, unit column stride, taps descend)
+template <int KW, int S, bool TKIND>
+__global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
+    constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
+    constexpr int TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ;
+    constexpr int SC = TKIND ? 1 : S;                 // window positions per column step
+    constexpr int STG = RTILE_A + NQ * RS;            // floats per LDS stage
+    static_assert(KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "raw-window kernels need 4/8/16/32 taps per channel");
+    static_assert(!TKIND || KW % S == 0, "T raw kernel needs s | k");
+    __shared__ __attribute__((aligned(16))) float lds[2 * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
+    const int kt = dma_kt(lane, wv);
+    const int Lcol = TKIND ? p.U : p.Ly;              // columns (output positions) per sample
+    const int Ktot = p.Q * KWP, Ntot = p.B * Lcol, Mrows = TKIND ? p.M * S : p.M;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
+    const int wq = p.M * KW;                          // T: weight stride between input channels
+    const int g = xcd_remap(blockIdx.x, gridDim.x);
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);
+    int pos = split_lo(sp, g);
+    const int pos_end = split_lo(sp, g + 1);
+    int slot = 0;
+    while (pos < pos_end) {
+        const int tile = pos / p.nslab, sb = pos - tile * p.nslab;
+        const int se = min(p.nslab, sb + (pos_end - pos));
+        const int m0 = (tile / p.tilesN) * RBM, n0 = (tile % p.tilesN) * RBN;
+        const int b0 = n0 / Lcol, t0 = n0 - b0 * Lcol;            // sample / position of the tile's first column
+        const int nseg = (t0 + RBN - 1) / Lcol + 1;
+        const int rlen = SC * (RBN - 1) + TJ + RG * (nseg - 1);   // floats of a channel window that are ever read
+
+        // --- weight-tile gather constants (BYTE offsets) --------------------------------------------------------
+        int aoff[8], avoff[2];
+        if (TKIND) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int mr = m0 + dma_row(lane, wv, e), o = mr / S, phi = mr - o * S;
+                aoff[e] = mr < Mrows ? (o * KW + phi) * 4 : FAR;              // W[q][o][S*jj + phi]
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = m0 + dma_row(lane, wv, e);
+                aoff[e] = (!p.a_vec && m < p.M) ? (m * Ktot + kt) * 4 : FAR;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int m = m0 + dma16_row(lane, wv, e);
+                avoff[e] = m < p.M ? (m * Ktot + dma16_kc(lane)) * 4 : FAR;
+            }
+        }
+        // --- window gather constants: thread owns window positions v = tid + 256 e --------------------------------
+        int posb[3], rowb[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int v = tid + 256 * e;
+            int k = 0;                                            // segment (sample) this window position belongs to
+            while (k + 1 < nseg && SC * ((k + 1) * Lcol - t0) + RG * (k + 1) <= v) ++k;
+            const int cs = k ? k * Lcol - t0 : 0;                 // first column of the segment
+            const int vl = v - (SC * cs + RG * k);                // position inside the segment's window
+            const int tf = k ? 0 : t0;                            // frame index of that first column
+            const int b = b0 + k;
+            // F: memory position = s*t - p + tau;  T: u - tau with u = u_off + t, stored ascending from u - (TJ-1)
+            posb[e] = b < p.B ? (TKIND ? p.u_off + tf - (TJ - 1) + vl : S * tf - p.p + vl) : -NEVER;
+            rowb[e] = b * (int)p.x_bs * 4;
+        }
+        // --- fragment bases: window offset of each of this lane's 4 columns ----------------------------------------
+        int bbase[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int c = wn * 128 + jb * 32 + (lane & 31);
+            bbase[jb] = SC * c + RG * ((t0 + c) / Lcol) + (TKIND ? TJ - 1 : 0);
+        }
+
+        AccR acc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;
+
+#define RAW_ISSUE(STAGE_PTR, K0)                                                                          \
+    {   float* const As = (STAGE_PTR) + wv * 64; float* const Bw = (STAGE_PTR) + RTILE_A + wv * 64;       \
+        const int k0 = (K0);                                                                              \
+        const bool kok = k0 < Ktot;                                                                       \
+        if (TKIND) {                                                                                      \
+            const int kk = k0 + kt, q = kk / KWP, jj = kk - q * KWP;                                      \
+            const int wo = kok ? (q * wq + S * jj) * 4 : OOB;                                             \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) dma4(rw, As + e * 256, aoff[e] + wo);           \
+        } else if (p.a_vec) {                                                                             \
+            const int kv = (k0 + dma16_kc(lane) < Ktot) ? k0 * 4 : OOB;                                   \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) dma16(rw, As + wv * 192 + e * 1024, avoff[e] + kv); \
+        } else {                                                                                          \
+            const int ka = (k0 + kt < Ktot) ? k0 * 4 : OOB;                                               \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) dma4(rw, As + e * 256, aoff[e] + ka);           \
+        }                                                                                                 \
+        const int q0 = k0 / KWP, tau0 = k0 - q0 * KWP;    /* tau0 != 0 only when a channel spans two slabs */ \
+        _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                               \
+            const int qq = q0 + qi;                                                                       \
+            const int qo = (kok && qq < p.Q) ? qq * p.Lx : -NEVER;                                        \
+            _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                               \
+                if (e * 256 + wv * 64 < rlen) {                                                           \
+                    const int ps = posb[e] + (TKIND ? -tau0 : tau0);                                      \
+                    const bool ok = (unsigned)ps < (unsigned)p.Lx && qo >= 0;                             \
+                    dma4(rx, Bw + qi * RS + e * 256, ok ? rowb[e] + (qo + ps) * 4 : FAR);                 \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+
+        RAW_ISSUE(lds, sb * BK)
+        __syncthreads();
+        for (int sl = sb; sl < se; ++sl) {
+            const int cur = (sl - sb) & 1;
+            RAW_ISSUE(lds + (cur ^ 1) * STG, (sl + 1) * BK)
+            __builtin_amdgcn_sched_barrier(0);
+            mma_slab_raw<TJ, TKIND>(lds + cur * STG, lds + cur * STG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+#undef RAW_ISSUE
+        if (sb == 0 && se == p.nslab) {
+            if (TKIND) epilogue_t<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+            else epilogue_f<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+        } else store_partial(p.ws, g, slot, acc, tid);
+        pos += se - sb;
+        slot = 1;
+    }
+}
+
 // ---- fixup: add the partial segments of every split tile in ascending workgroup order, then the epilogue ---------
-template <int KIND>
+template <int KIND, int MB, int NB>
 __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int G) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
     const int tile = blockIdx.x;
@@ -469,27 +672,27 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
     const int first = tile * p.nslab, last = first + p.nslab - 1;
     const int g0 = split_owner(sp, first), g1 = split_owner(sp, last);
     if (g0 == g1 && split_lo(sp, g0) <= first && split_lo(sp, g0 + 1) > last) return;   // computed whole by one workgroup
-    Acc acc;
+    AccT<MB, NB> acc;
 #pragma unroll
-    for (int i = 0; i < WMB; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;
     for (int g = g0; g <= g1; ++g) {
         const int slot = (split_lo(sp, g) / p.nslab == tile) ? 0 : 1;     // the range's first segment, or its last
         const float* src = p.ws + ((long)(g * 2 + slot) * ACC_REGS) * NT + tid;
 #pragma unroll
-        for (int i = 0; i < WMB; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc.c[i][j][r] += src[((i * 2 + j) * 16 + r) * NT];
+                for (int r = 0; r < 16; ++r) acc.c[i][j][r] += src[((i * NB + j) * 16 + r) * NT];
     }
-    const int m0 = (tile / p.tilesN) * BM, n0 = (tile % p.tilesN) * BN;
-    if (KIND == 0) epilogue_f<0>(p, acc, m0, n0, lane, wm, wn);
-    else if (KIND == 1) epilogue_t<0>(p, acc, m0, n0, lane, wm, wn);
-    else epilogue_g<0>(p, acc, m0, n0, lane, wm, wn);
+    const int m0 = (tile / p.tilesN) * (64 * MB), n0 = (tile % p.tilesN) * (64 * NB);
+    if (KIND == 0) epilogue_f<0, MB, NB>(p, acc, m0, n0, lane, wm, wn);
+    else if (KIND == 1) epilogue_t<0, MB, NB>(p, acc, m0, n0, lane, wm, wn);
+    else epilogue_g<0, MB, NB>(p, acc, m0, n0, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -539,27 +742,65 @@ int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mo
     return balance < 0.93 ? (int)G : (int)tiles;
 }
 
-int g_force_mode = 0;   // test hook, set through pg_conv_set_schedule()
+int g_force_mode = 0;   // test hook, set through pg_conv_set_schedule(): work split
+int g_force_raw = 0;    // test hook: 1 = never use the raw-window kernels (exercise the im2col F/T kernels)
+
+// raw-window kernels: supported (k, s) pairs and the window-length bound
+bool raw_supported(Kind kind, const IgemmParams& p) {
+    if (g_force_raw == 1) return false;
+    int kwp, sc, lcol;
+    if (kind == KIND_F) {
+        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
+        kwp = p.k; sc = p.s; lcol = p.Ly;
+    } else if (kind == KIND_T) {
+        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2))) return false;
+        kwp = p.k / p.s; sc = 1; lcol = p.U;
+    } else return false;
+    const int tj = kwp < 16 ? kwp : 16;
+    const int nseg_max = (lcol - 1 + RBN - 1) / lcol + 1;
+    return sc * (RBN - 1) + tj + RG * (nseg_max - 1) + (kind == KIND_T ? tj : 0) <= RS;
+}
+
+template <int KW, int S, bool TK>
+hipError_t launch_raw(const IgemmParams& p, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK>), dim3(grid), dim3(NT), 0, st, p);
+    return hipGetLastError();
+}
 
 int launch(Kind kind, IgemmParams& p, long rows, long cols, long Ktot, long ws_bytes, hipStream_t st) {
-    p.tilesM = (int)((rows + BM - 1) / BM);
-    p.tilesN = (int)((cols + BN - 1) / BN);
+    const bool raw = raw_supported(kind, p);
+    const int bm = raw ? RBM : BM, bn = raw ? RBN : BN;
+    p.tilesM = (int)((rows + bm - 1) / bm);
+    p.tilesN = (int)((cols + bn - 1) / bn);
     p.nslab = (int)((Ktot + BK - 1) / BK);
     const long tiles = (long)p.tilesM * p.tilesN;
     if (tiles <= 0 || tiles > 0x7fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");
     const int grid = pick_grid(tiles, p.nslab, p, ws_bytes, g_force_mode);
     hipError_t e;
-    if (p.k == 32 && p.s == 2) e = launch_kind<32, 2>(kind, p, grid, st);
+    if (raw && kind == KIND_F) {
+        if (p.k == 32) e = launch_raw<32, 2, false>(p, grid, st);
+        else if (p.k == 8 && p.s == 1) e = launch_raw<8, 1, false>(p, grid, st);
+        else if (p.k == 8) e = launch_raw<8, 2, false>(p, grid, st);
+        else e = launch_raw<4, 2, false>(p, grid, st);
+    } else if (raw) {
+        if (p.k == 32) e = launch_raw<32, 2, true>(p, grid, st);
+        else if (p.s == 1) e = launch_raw<8, 1, true>(p, grid, st);
+        else e = launch_raw<8, 2, true>(p, grid, st);
+    }
+    else if (p.k == 32 && p.s == 2) e = launch_kind<32, 2>(kind, p, grid, st);
     else if (p.k == 8 && p.s == 1) e = launch_kind<8, 1>(kind, p, grid, st);
     else if (p.k == 8 && p.s == 2) e = launch_kind<8, 2>(kind, p, grid, st);
     else if (p.k == 4 && p.s == 2) e = launch_kind<4, 2>(kind, p, grid, st);
     else if (p.k == 5 && p.s == 2) e = launch_kind<5, 2>(kind, p, grid, st);
     else e = launch_kind<0, 0>(kind, p, grid, st);
     if (e == hipSuccess && grid != tiles) {
-        switch (kind) {
-            case KIND_F: hipLaunchKernelGGL((conv_fixup_kernel<0>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
-            case KIND_T: hipLaunchKernelGGL((conv_fixup_kernel<1>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
-            case KIND_G: hipLaunchKernelGGL((conv_fixup_kernel<2>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
+        if (raw) {
+            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid);
+            else hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid);
+        } else switch (kind) {
+            case KIND_F: hipLaunchKernelGGL((conv_fixup_kernel<0, WMB, 2>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
+            case KIND_T: hipLaunchKernelGGL((conv_fixup_kernel<1, WMB, 2>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
+            case KIND_G: hipLaunchKernelGGL((conv_fixup_kernel<2, WMB, 2>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
         }
         e = hipGetLastError();
     }
@@ -695,7 +936,9 @@ extern "C" int64_t pg_workspace_bytes_conv(void) { return (int64_t)MAX_STREAMK_W
 
 // Test hook: 0 = automatic schedule, 1 = force one tile per workgroup, 2 = force stream-K (needs a workspace).
 extern "C" int pg_conv_set_schedule(int mode) {
-    if (mode < 0 || mode > 2) return pg_fail(PG_ERR_SHAPE, "conv_set_schedule: mode must be 0, 1 or 2");
-    g_force_mode = mode;
+    // bits 0-1: 0 automatic split, 1 one tile per workgroup, 2 force stream-K;  bit 2: disable the raw-window kernels
+    if (mode < 0 || mode > 7 || (mode & 3) == 3) return pg_fail(PG_ERR_SHAPE, "conv_set_schedule: bad mode");
+    g_force_mode = mode & 3;
+    g_force_raw = (mode >> 2) & 1;
     return PG_OK;
 }
