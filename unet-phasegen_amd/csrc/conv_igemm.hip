@@ -643,16 +643,22 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         }                                                                                                 \
     }
 
+        PG_STAMP_DECL
         RAW_ISSUE(lds, sb * BK)
         __syncthreads();
         for (int sl = sb; sl < se; ++sl) {
             const int cur = (sl - sb) & 1;
+            PG_STAMP(0)
             RAW_ISSUE(lds + (cur ^ 1) * STG, (sl + 1) * BK)
             __builtin_amdgcn_sched_barrier(0);
+            PG_STAMP(1)
             mma_slab_raw<TJ, TKIND>(lds + cur * STG, lds + cur * STG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
             __builtin_amdgcn_sched_barrier(0);
+            PG_STAMP(2)
             __syncthreads();
+            PG_STAMP(3)
         }
+        PG_STAMP_FLUSH
 #undef RAW_ISSUE
         if (sb == 0 && se == p.nslab) {
             if (TKIND) epilogue_t<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);

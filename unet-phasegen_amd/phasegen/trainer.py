@@ -50,16 +50,17 @@ class BucketedAllReduce:
     the layer's wgrad has been enqueued; ``wait_all()`` before the optimiser step.  The 1/world averaging is NOT
     applied here: Adam folds it into its single pass over the arena (grad_scale)."""
 
-    def __init__(self, arena, group=None):
+    def __init__(self, arena, group=None, always=False):
         self.buckets = GradBuckets(arena)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.always = always and dist.is_available() and dist.is_initialized()   # run the collective even at world 1 (tests)
         self.pending = []
         self.launched = []
 
     def launch(self, name):
         self.launched.append(name)
-        if self.world > 1:
+        if self.world > 1 or self.always:
             self.pending.append(dist.all_reduce(self.buckets.view(name), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait_all(self):
@@ -71,11 +72,11 @@ class BucketedAllReduce:
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, mag_weight=0.2):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, mag_weight=0.2, always_reduce=False):
         self.model = model
         self.engine = model.engine
         self.optim = Adam(model.parameters(), lr=lr, betas=betas, eps=eps)
-        self.reducer = BucketedAllReduce(self.engine.arena, group)
+        self.reducer = BucketedAllReduce(self.engine.arena, group, always=always_reduce)
         self.world = self.reducer.world
         self.mag_weight = mag_weight
         self.losses = torch.zeros(3, device=self.engine.device)
