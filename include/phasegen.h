@@ -130,6 +130,17 @@ typedef struct pg_istft_args {
 int64_t pg_workspace_bytes_istft(const pg_istft_args* a);
 int pg_istft(const pg_istft_args* a, void* stream);
 
+/* Griffin-Lim building blocks (utils.py:112-134).  pg_gl_project: S (2,bins,frames) = [re; im] of the current estimate's
+ * STFT and the target magnitudes mag (bins,frames) -> new_spec = mag * exp(j angle(S)) written as (2,bins,frames) to
+ * spec_out (may be NULL) and, laid out as the operand of the inverse-DFT GEMM, to x (2*bins-2, frames): rows 0..bins-1
+ * real parts, rows bins.. imaginary parts of bins 1..bins-2 (DC/Nyquist imaginary parts are ignored by an irfft).
+ * pg_ola_nt: overlap-add of windowed frames given as (n_fft, frames) [n][t], any even n_fft (the reference inverts the
+ * DC-dropped matrix, n_fft = 2*(bins-1) = 2046), / window-sum-square, trim n_fft/2, optional peak normalisation. */
+typedef struct pg_gl_args { int32_t bins, frames; const float* S; const float* mag; float* x; float* spec_out; } pg_gl_args;
+int pg_gl_project(const pg_gl_args* a, void* stream);
+typedef struct pg_ola_args { int32_t n_fft, frames, hop, normalize; const float* fr; float* audio; void* workspace; int64_t workspace_bytes; } pg_ola_args;
+int pg_ola_nt(const pg_ola_args* a, void* stream);   /* workspace: 256 bytes */
+
 /* small helpers the training step needs on device */
 int pg_fill(float* p, int64_t n, float value, void* stream);
 

@@ -29,14 +29,24 @@ def test_train_then_demo(tmp_path):
     np.save(tmp_path / "dataset" / "Pop_audio_train.npy", arr)
     np.save(tmp_path / "dataset" / "Pop_audio_val.npy", arr[:3])
     out = run([os.path.join(PKG, "train.py"), "--channels", str(C), "--batch_size", "2", "--max_steps", "6", "--ckpt_every", "4",
-               "--log_dir", "unet_llr/"], cwd=str(tmp_path))
+               "--log_dir", "unet_llr/", "--val_every", "3", "--gl_iters", "5", "--hop", str(hop), "--n_fft", str(n_fft)], cwd=str(tmp_path))
     assert "start loading" in out and "Epoch 1 done," in out and "mag loss:" in out and "ang loss:" in out
     ckpt = tmp_path / "unet_llr" / "ckpt_4"
-    assert ckpt.exists() and (tmp_path / "unet_llr" / "log.jsonl").exists()
+    assert ckpt.exists() and (tmp_path / "unet_llr" / "ckpt_4.optim").exists()
+    import json
+    lines = [json.loads(l) for l in open(tmp_path / "unet_llr" / "log.jsonl")]
+    val = [l for l in lines if "LMSE" in l]
+    assert len(val) == 2 and all(np.isfinite([v["MSE"], v["NOPMSE"], v["LMSE"]]).all() for v in val)   # steps 3 and 6
+    # resume from step 4 and continue
+    out2 = run([os.path.join(PKG, "train.py"), "--channels", str(C), "--batch_size", "2", "--max_steps", "2", "--log_dir", "unet_llr2/",
+                "--resume", str(ckpt), "--val_every", "1000"], cwd=str(tmp_path))
+    assert "Epoch 1 done," in out2
     out = run([os.path.join(PKG, "demo.py"), "--genre", "Pop", "--n_songs", "2", "--n_fft", str(n_fft), "--hop", str(hop),
                "--weight", str(ckpt), "--channels", str(C)], cwd=str(tmp_path))
-    assert "UNet - avg" in out and "sec per clip." in out
+    assert "UNet - avg" in out and "sec per clip." in out and "GL - avg" in out and "sec per clip" in out
     from scipy.io import wavfile
     for c in range(2):
         sr, a = wavfile.read(tmp_path / "demo" / f"unet_Pop_{c}.wav")
         assert sr == 16000 and a.dtype == np.float32 and a.shape == (hop * (L - 1),) and abs(np.max(np.abs(a)) - 1) < 1e-5
+        sr, gl = wavfile.read(tmp_path / "demo" / f"gl_Pop_{c}.wav")                  # demo.py:58 Griffin-Lim comparator
+        assert gl.shape == a.shape and abs(np.max(np.abs(gl)) - 1) < 1e-5

@@ -161,3 +161,24 @@ def test_loader_semantics(tmp_path):
     assert (n0, n1) == (3, 2)                                                          # clips r::W of one shared permutation
     with pytest.raises(AssertionError):
         get_fft_npy_loader([str(tmp_path / "nope.npy")])
+
+
+@pytest.mark.parametrize("n_fft,hop,frames,n_iter", [(64, 16, 32, 4), (2048, 512, 128, 3), (1024, 256, 24, 2)])
+def test_griffin_lim_vs_oracle(n_fft, hop, frames, n_iter):
+    """Row N1 (utils.py:85-134), including the reference's quirk of inverting the DC-dropped matrix with n_fft - 2 points
+    (2046 for 2048): on device that inverse transform is a 1x1 convolution with a synthesis matrix on the MFMA kernel."""
+    from phasegen import audio
+    n = hop * (frames - 1)
+    y = detgen.make_clip(n, seed=60)
+    mag = np.abs(np.delete(signal_ref.stft(y, n_fft, hop), 0, axis=0)).astype(np.float32)
+    init = detgen.normal(61, (n,)).astype(np.float64)
+    want_a, want_s, want_l = signal_ref.griffin_lim(mag, n_fft, hop, n_iter, init)
+    got_a, got_s, got_l = audio.griffin_lim(mag, n_fft, hop, n_iter, init=init)
+    assert got_a.shape == want_a.shape == (n,) and got_s.shape == want_s.shape
+    assert relmax(got_a, want_a) < 2e-3
+    assert np.max(np.abs(got_s - want_s)) < 2e-3 * np.max(np.abs(want_s))
+    assert abs(got_l - want_l) < 2e-3 * abs(want_l)
+    assert abs(np.max(np.abs(got_a)) - 1.0) < 1e-6
+    a2, _, _ = audio.griffin_lim(mag, n_fft, hop, n_iter, seed=7)      # seeded random start: reproducible
+    a3, _, _ = audio.griffin_lim(mag, n_fft, hop, n_iter, seed=7)
+    assert np.array_equal(a2, a3)

@@ -166,6 +166,52 @@ __global__ __launch_bounds__(256) void istft_normalize_kernel(float* audio, int 
         audio[(long)sig * len + i] /= pk;
 }
 
+// Griffin-Lim projection onto the target magnitudes: keep the phase of S, impose mag (utils.py:122-124)
+__global__ __launch_bounds__(256) void gl_project_kernel(const pg_gl_args a) {
+    const long total = (long)a.bins * a.frames;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / a.frames), t = (int)(e - (long)r * a.frames);
+        float re = a.S[e], im = a.S[total + e];
+        pg_complex_from_parts(re, im);                      // np.angle on re + 1j*im
+        const float mod = hypotf(re, im), m = a.mag[e];
+        const float c = mod > 0.f ? re / mod : 1.f, s = mod > 0.f ? im / mod : 0.f;   // angle(0) = 0
+        const float nr = m * c, ni = m * s;
+        if (a.spec_out) { a.spec_out[e] = nr; a.spec_out[total + e] = ni; }
+        a.x[e] = nr;
+        if (r >= 1 && r <= a.bins - 2) a.x[(long)(a.bins + r - 1) * a.frames + t] = ni;
+    }
+}
+
+// overlap-add of (n_fft, frames)-major windowed frames, any even n_fft
+__global__ __launch_bounds__(256) void ola_nt_kernel(const pg_ola_args a, unsigned* peak) {
+    __shared__ float scratch[16];
+    const int N = a.n_fft, len = a.hop * (a.frames - 1);
+    float mx = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+        const int ip = i + (N >> 1);
+        int t_hi = ip / a.hop; if (t_hi > a.frames - 1) t_hi = a.frames - 1;
+        int t_lo = (ip - N + a.hop) / a.hop; if (ip - N + 1 <= 0) t_lo = 0;
+        float s = 0.f, wss = 0.f;
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const int n = ip - t * a.hop;
+            const float w = hann(n, N);
+            s += a.fr[(long)n * a.frames + t];
+            wss += w * w;
+        }
+        const float yv = wss > 1.17549435e-38f ? s / wss : s;
+        a.audio[i] = yv;
+        mx = fmaxf(mx, fabsf(yv));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) mx = fmaxf(mx, scratch[i]);
+        atomicMax(peak, __float_as_uint(mx));
+    }
+}
+
 bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 }  // namespace
@@ -213,6 +259,31 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
     int bx = (len + 255) / 256; if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(istft_ola_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, *a, (const float*)frames, peak);
     if (a->normalize) hipLaunchKernelGGL(istft_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const unsigned*)peak);
+    e = hipGetLastError();
+    return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
+}
+
+extern "C" int pg_gl_project(const pg_gl_args* a, void* stream) {
+    if (!a || !a->S || !a->mag || !a->x) return pg_fail(PG_ERR_NULL, "gl_project: S, mag, x required");
+    if (a->bins < 3 || a->frames <= 0) return pg_fail(PG_ERR_SHAPE, "gl_project: bad sizes");
+    long blocks = ((long)a->bins * a->frames + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gl_project_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
+}
+
+extern "C" int pg_ola_nt(const pg_ola_args* a, void* stream) {
+    if (!a || !a->fr || !a->audio || !a->workspace) return pg_fail(PG_ERR_NULL, "ola_nt: fr, audio, workspace required");
+    if (a->n_fft < 4 || (a->n_fft & 1) || a->frames < 2 || a->hop <= 0 || a->hop > a->n_fft) return pg_fail(PG_ERR_SHAPE, "ola_nt: bad sizes");
+    if (a->workspace_bytes < 256) return pg_fail(PG_ERR_WORKSPACE, "ola_nt: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* peak = (unsigned*)a->workspace;
+    hipError_t e = hipMemsetAsync(peak, 0, 256, st);
+    if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
+    const int len = a->hop * (a->frames - 1);
+    int bx = (len + 255) / 256; if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(ola_nt_kernel, dim3(bx), dim3(256), 0, st, *a, peak);
+    if (a->normalize) hipLaunchKernelGGL(istft_normalize_kernel, dim3(bx, 1), dim3(256), 0, st, a->audio, len, (const unsigned*)peak);
     e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
 }

@@ -68,6 +68,16 @@ class IstftArgs(C.Structure):
                 ("audio", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
+class GlArgs(C.Structure):
+    _fields_ = [("bins", C.c_int32), ("frames", C.c_int32), ("S", C.c_void_p), ("mag", C.c_void_p), ("x", C.c_void_p),
+                ("spec_out", C.c_void_p)]
+
+
+class OlaArgs(C.Structure):
+    _fields_ = [("n_fft", C.c_int32), ("frames", C.c_int32), ("hop", C.c_int32), ("normalize", C.c_int32),
+                ("fr", C.c_void_p), ("audio", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
 # every symbol include/phasegen.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "pg_conv1d_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
@@ -88,6 +98,8 @@ SYMBOLS = {
     "pg_polar": (C.c_int, [C.POINTER(PolarArgs), C.c_void_p]),
     "pg_workspace_bytes_istft": (C.c_int64, [C.POINTER(IstftArgs)]),
     "pg_istft": (C.c_int, [C.POINTER(IstftArgs), C.c_void_p]),
+    "pg_gl_project": (C.c_int, [C.POINTER(GlArgs), C.c_void_p]),
+    "pg_ola_nt": (C.c_int, [C.POINTER(OlaArgs), C.c_void_p]),
     "pg_fill": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "pg_version": (C.c_int, []),
     "pg_last_error_string": (C.c_char_p, []),

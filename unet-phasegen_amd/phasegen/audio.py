@@ -45,3 +45,67 @@ def synthesize(logmag, phase, hop_length, normalize=True):
     """demo.py:39-40 fused on device: istft((exp(logmag) - 1) * exp(1j * phase)) for a batch of clips.
     logmag, phase: (n, bins, frames) device tensors (phase may be the first half of the network output) -> (n, samples)."""
     return ops.istft(logmag, phase, hop_length, mode=0, normalize=normalize)
+
+
+_synth = {}
+
+
+def _synthesis_matrix(bins, device):
+    """Inverse real DFT of the reference's Griffin-Lim as a (n, 2*bins-2) matrix: n_fft' = 2*(bins-1) (utils.py:114,127
+    invert the DC-DROPPED matrix, so 1024 rows mean a 2046-point transform), periodic Hann and 1/n_fft' folded in.
+    Columns: Re of bins 0..bins-1, then Im of bins 1..bins-2."""
+    key = (bins, str(device))
+    if key not in _synth:
+        N = 2 * (bins - 1)
+        n = np.arange(N, dtype=np.float64)[:, None]
+        k = np.arange(bins, dtype=np.float64)[None, :]
+        win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / N)
+        cw = np.where((k == 0) | (k == bins - 1), 1.0, 2.0)
+        Wre = cw * np.cos(2.0 * np.pi * k * n / N)
+        Wim = -2.0 * np.sin(2.0 * np.pi * k[:, 1:bins - 1] * n / N)
+        W = np.concatenate([Wre, Wim], axis=1) * win / N
+        _synth[key] = torch.from_numpy(W.astype(np.float32)).to(device)[:, :, None].contiguous()
+    return _synth[key]
+
+
+def griffin_lim(spec, n_fft, hop_length, n_iter, init=None, seed=None):
+    """utils.py:85-134 on device.  ``spec``: magnitudes (n_fft/2, frames) (DC already dropped).  Each iteration:
+    STFT (pg_stft) -> keep phase, impose magnitude (pg_gl_project) -> inverse transform as a 1x1 convolution on the
+    fp32-MFMA conv kernel with the synthesis matrix above -> overlap-add (pg_ola_nt).  The start vector replaces
+    ``np.random.randn`` (utils.py:116): pass ``init`` or a ``seed`` for a reproducible one.
+    Returns (audio float32 numpy peak-normalised, new_spec complex numpy, loss float) like the reference."""
+    dev = _dev()
+    mag = torch.from_numpy(np.ascontiguousarray(np.abs(spec) if np.iscomplexobj(spec) else spec, dtype=np.float32)).to(dev)
+    bins, frames = mag.shape
+    if bins != n_fft // 2:
+        raise ValueError(f"griffin_lim: spec has {bins} rows, expected n_fft/2 = {n_fft // 2}")
+    length = hop_length * (frames - 1)
+    if init is None:
+        g = torch.Generator(device="cpu")
+        g.manual_seed(torch.initial_seed() if seed is None else seed)
+        init = torch.randn(length, generator=g, dtype=torch.float64).numpy()
+    recon = torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32)).to(dev)
+    W = _synthesis_matrix(bins, dev)
+    N = 2 * (bins - 1)
+    x = torch.zeros(1, N, frames, device=dev)
+    fr = torch.empty(1, N, frames, device=dev)
+    S = torch.empty(1, 2, bins, frames, device=dev)
+    new_spec = torch.empty(2, bins, frames, device=dev)
+    prev = torch.empty_like(recon)
+    loss = float("nan")
+    for _ in range(n_iter):
+        ops.stft(recon[None], n_fft, hop_length, out=S)
+        ops.gl_project(S[0], mag, x[0], new_spec)
+        ops.conv_fwd(x, W, fr, 1, 0)
+        prev.copy_(recon)
+        ops.ola_nt(fr[0], hop_length, recon)
+    if n_iter > 0:
+        loss = float(torch.sqrt(torch.sum((recon - prev) ** 2) / recon.numel()))
+    audio = recon.cpu().numpy()
+    if not np.all(np.isfinite(audio)):
+        raise ValueError("Audio buffer is not finite everywhere")
+    peak = np.max(np.abs(audio))
+    if peak > np.finfo(np.float32).tiny:
+        audio = audio / peak
+    ns = new_spec.cpu().numpy()
+    return audio, (ns[0] + 1j * ns[1]).astype(np.complex64), loss

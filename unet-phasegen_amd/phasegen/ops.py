@@ -298,3 +298,30 @@ def istft(a_t, b_t, hop, mode=0, normalize=True):
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(lib.pg_istft(C.byref(a), _stream()), "istft")
     return audio
+
+
+def gl_project(S, mag, x, spec_out=None):
+    """utils.py:122-124: new_spec = mag * exp(1j * angle(S)) -> GEMM operand x (2*bins-2, frames) (+ [re; im] copy)."""
+    a = _lib.GlArgs()
+    a.bins, a.frames = mag.shape
+    a.S, a.mag, a.x = _dense(S, "S"), _dense(mag, "mag"), _dense(x, "x")
+    if spec_out is not None:
+        a.spec_out = _dense(spec_out, "spec_out")
+    _lib.check(_lib.load().pg_gl_project(C.byref(a), _stream()), "gl_project")
+
+
+_ola_ws = {}
+
+
+def ola_nt(frames_nt, hop, audio, normalize=False):
+    """Overlap-add of (n_fft, frames)-major windowed frames (any even n_fft) into ``audio`` (hop * (frames - 1),)."""
+    a = _lib.OlaArgs()
+    a.n_fft, a.frames = frames_nt.shape
+    a.hop, a.normalize = hop, int(normalize)
+    a.fr, a.audio = _dense(frames_nt, "frames"), _dense(audio, "audio")
+    ws = _ola_ws.get(audio.device)
+    if ws is None:
+        ws = _ola_ws[audio.device] = torch.empty(256, device=audio.device, dtype=torch.uint8)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), 256
+    _lib.check(_lib.load().pg_ola_nt(C.byref(a), _stream()), "ola_nt")
+    return audio

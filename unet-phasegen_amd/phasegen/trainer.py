@@ -93,3 +93,21 @@ class Trainer:
         self.reducer.wait_all()
         self.optim.step(grad_scale=1.0 / self.world)
         return self.losses
+
+
+    # -- checkpoint / resume.  The reference saves the model only (model.py:45-48) and cannot
+    # resume; the model file keeps that exact format (UNetModel.save) and the optimiser state goes next to it.
+    def save_checkpoint(self, path):
+        self.model.save(path)
+        o = self.optim
+        torch.save({"step": o.step_count, "lr": o.param_groups[0]["lr"], "betas": o.betas, "eps": o.eps,
+                    "exp_avg": o.m.cpu(), "exp_avg_sq": o.v.cpu()}, path + ".optim")
+
+    def load_checkpoint(self, path):
+        self.model.load(path)
+        sd = torch.load(path + ".optim", map_location="cpu", weights_only=True)
+        o = self.optim
+        o.step_count = int(sd["step"])
+        o.param_groups[0]["lr"] = float(sd["lr"])
+        o.m.copy_(sd["exp_avg"])
+        o.v.copy_(sd["exp_avg_sq"])

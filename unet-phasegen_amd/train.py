@@ -32,6 +32,13 @@ def main():
     ap.add_argument("--lr", type=float, default=0.001)                        # train.py:26
     ap.add_argument("--max_steps", type=int, default=0, help="stop after this many steps (0 = run forever like the reference)")
     ap.add_argument("--ckpt_every", type=int, default=4000)                   # train.py:126
+    ap.add_argument("--val", default="dataset/Pop_audio_val.npy")             # train.py:23
+    ap.add_argument("--val_every", type=int, default=2000)                    # train.py:69
+    ap.add_argument("--val_clips", type=int, default=3)                       # train.py:24 batch_size=3
+    ap.add_argument("--gl_iters", type=int, default=250)                      # train.py:101
+    ap.add_argument("--hop", type=int, default=512)
+    ap.add_argument("--n_fft", type=int, default=2048)
+    ap.add_argument("--resume", default=None, help="checkpoint written by a previous run (ckpt_N + ckpt_N.optim)")
     ap.add_argument("--synthetic", type=int, default=0, help="train on N synthetic clips instead of --train (no dataset ships)")
     ap.add_argument("--frames", type=int, default=128, help="frames per synthetic clip")
     a = ap.parse_args()
@@ -43,6 +50,7 @@ def main():
     from phasegen.data import SpectrogramLoader, get_fft_npy_loader
     from phasegen.model import UNetModel
     from phasegen.trainer import Trainer
+    from phasegen.validate import validation_metrics
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     gpu_id = a.gpu if a.gpu is not None else int(os.environ.get("LOCAL_RANK", "0"))
@@ -57,6 +65,11 @@ def main():
     else:
         loader = get_fft_npy_loader([a.train], [0, 1], batch_size=a.batch_size, precon=True, rank=rank, world=world, seed=0)
     trainer = Trainer(model, lr=a.lr)
+    if a.resume:
+        trainer.load_checkpoint(a.resume)
+    val_loader = None
+    if not a.synthetic and os.path.exists(a.val) and rank == 0:
+        val_loader = get_fft_npy_loader([a.val], [0, 1], batch_size=a.val_clips, precon=True, seed=0)
     os.makedirs(a.log_dir, exist_ok=True)
     log = open(os.path.join(a.log_dir, "log.jsonl"), "a") if rank == 0 else None
 
@@ -76,8 +89,13 @@ def main():
             mag_sum += losses[2]
             n_loss += 1
             frames += d[0].size(0) * d[0].size(3) * world
+            if cnt % a.val_every == 0 and val_loader is not None:              # train.py:69-124 (metrics only, JSONL)
+                vm = validation_metrics(model, val_loader.__iter__().__next__()[0], a.hop, a.n_fft, a.gl_iters)
+                vm["steps"] = cnt
+                log.write(json.dumps(vm) + "\n")
+                log.flush()
             if cnt % a.ckpt_every == 0 and rank == 0:
-                model.save(a.log_dir + "/ckpt_{}".format(cnt))                # train.py:126-127
+                trainer.save_checkpoint(a.log_dir + "/ckpt_{}".format(cnt))   # train.py:126-127 (+ optimiser state)
             if a.max_steps and cnt >= a.max_steps:
                 break
         j += 1
