@@ -182,3 +182,32 @@ def test_griffin_lim_vs_oracle(n_fft, hop, frames, n_iter):
     a2, _, _ = audio.griffin_lim(mag, n_fft, hop, n_iter, seed=7)      # seeded random start: reproducible
     a3, _, _ = audio.griffin_lim(mag, n_fft, hop, n_iter, seed=7)
     assert np.array_equal(a2, a3)
+
+
+def test_preproc_chunker_matches_reference_algorithm(tmp_path):
+    """Row N2 (preproc_mdb.py:66-97,174-196): same chunk starts, zero-padded tails, STFT layout, whole-array
+    normalisation and shuffled split as a numpy restatement driven by the same Generator."""
+    from phasegen import preproc
+    n_fft, hop, rsr, sec = 64, 16, 1000, 0.496                  # t_slice = 496 samples -> 32 frames
+    t_slice = int(sec * rsr)
+    tracks = [detgen.make_clip(1300, seed=80), detgen.make_clip(700, seed=81)]
+    train, val = preproc.build_dataset(tracks, sec, rsr, n_fft, hop, n_random=2, n_val=3, seed=5, out_dir=str(tmp_path))
+    # numpy restatement
+    rng = np.random.default_rng(5)
+    chunks = []
+    for a in tracks:
+        for st in preproc.chunk_starts(len(a), t_slice, 2, rng):
+            c = a[st:st + t_slice]
+            if len(c) < t_slice:
+                c = np.pad(c, (0, t_slice - len(c)), "constant")
+            chunks.append(signal_ref.chunk_and_stft(c, n_fft, hop))
+    x = np.asarray(chunks, dtype=np.float32)
+    x = (x - x.mean()) / x.std()
+    idx = np.linspace(0, len(x) - 1, len(x), dtype=int)
+    rng.shuffle(idx)
+    assert val.shape == (3, 2, 32, 32) and train.shape == (len(x) - 3, 2, 32, 32) and train.dtype == np.float32
+    assert np.max(np.abs(val - x[idx][:3])) < 5e-5 and np.max(np.abs(train - x[idx][3:])) < 5e-5
+    assert os.path.exists(tmp_path / "Pop_audio_train.npy")
+    from phasegen.data import get_fft_npy_loader                       # and the loader consumes what preproc wrote
+    ld = get_fft_npy_loader([str(tmp_path / "Pop_audio_train.npy")], batch_size=4, precon=True)
+    assert next(iter(ld))[0].shape == (4, 2, 32, 32)
