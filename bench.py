@@ -7,11 +7,11 @@
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
-  roofline     dominant kernel (U0 forward = conv_t_kernel<32,2>, the largest single GEMM: 4.43 TFLOP per launch at
+  roofline     dominant kernel (U0 forward = conv_raw_kernel<32,2,true>, the largest single GEMM: 4.43 TFLOP per launch at
                batch 64) -- algorithmic FLOPs per launch / its average launch duration measured here with HIP events
                on the launch stream, against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
   cpu_baseline the oracle (CPU restatement of the reference, oracle/unet_ref.py) doing the SAME training step on the
-               host cores on a bounded sample (batch 1 of the same C=1024, L=256 model); rank 0, N = 1 only.
+               host cores on a bounded sample (batch 4 of the same C=1024, L=256 model); rank 0, N = 1 only.
   kernels      per-layer conv timings (ms, TFLOP/s) for DESIGN.md's table.
 """
 import argparse
@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "unet-phasegen_amd"))
 sys.path.insert(0, ROOT)
 
+DOMINANT_KERNEL = "conv_raw_kernel<32, 2, true>"   # the symbol rocprofv3 reports for the U0 forward launch
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 
 
@@ -64,13 +65,13 @@ def pmc_traffic(kernel_substr):
 
 
 def cpu_baseline(C, L, max_threads=None):
-    """One oracle training step at batch 1 on the host (bounded sample: ~10-40 s of CPU work)."""
+    """One oracle training step at batch 4 on the host (bounded sample: ~10-20 s of CPU work on 16 threads)."""
     import torch
     from oracle import unet_ref
     from phasegen import detgen
     threads = max_threads or host_threads()
     torch.set_num_threads(threads)
-    B = 1
+    B = 4
     shapes = detgen.conv_shapes(C)
     g = torch.Generator().manual_seed(0)
     p = {}
@@ -179,10 +180,10 @@ def main():
                                    f"UNetModel({C}, {2 * C}), per-GPU batch {B} x {C} bins x {L} frames (BASELINE configs[2]{'/[3]' if world > 1 else ''})",
                        "global_batch": world * B, "frames": L, "channels": C, "parallelism": f"dp{world}",
                        "final_loss": loss_val},
-            "roofline": {"bound": "mfma", "kernel": "conv_t_kernel<32,2> (U0 forward, ConvTranspose1d 4096->2048 k32 s2)",
+            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (U0 forward, ConvTranspose1d 4096->2048 k32 s2)",
                          "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic("conv_t_kernel<32, 2>") if (C, L, B) == (1024, 256, 64) else None,
+                         "traffic": pmc_traffic(DOMINANT_KERNEL) if (C, L, B) == (1024, 256, 64) else None,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                          "flops_per_launch": fl["U0"], "ms_per_launch": dom["ms"],
                          "step_tflops": round((3 * sum(fl.values()) - fl["D0"]) / (dt / a.steps) / 1e12, 2)},

@@ -10,14 +10,25 @@
 //   G ("gradient of W"):   dW[m][q][j] = sum_{b,i} actP(P[b,m,i]) * actQ(Q[b,q,s*i+j-p])
 //        = wgrad of both (conv: P=dy, Q=x; convT: P=x, Q=dy); beta = 0 write (zero_grad folded in).
 //
-// Tiling (all three): 256 threads = 4 waves in a 2x2 grid, workgroup tile 128x128, wave tile 64x64 = 2x2 MFMA
-// 32x32 accumulators (64 VGPRs), BK = 16.  Operand tiles live in LDS K-contiguous ([row][BK] with an 80-B row
-// stride => conflict-free ds_read_b128); lane half h = lane>>5 owns k in [8h, 8h+8) of each BK slab, so one lane
-// fetches its 8 A (or B) values of a 32-row block with two ds_read_b128 instead of eight ds_read_b32 (the MFMA
-// only needs A and B to agree on which k each lane half carries).  Global -> register -> LDS double buffering
-// with one barrier per BK slab; activations / zero padding / im2col indexing are applied while staging, so the
-// (Leaky)ReLU in front of every conv (model.py:91,96,103) and torch.cat (model.py:113) are never materialised.
-// Each output element is produced by exactly one workgroup in a fixed k order: results are deterministic.
+// Two generations of kernels live here, selected per launch by the host (launch()):
+//
+//  * RAW-WINDOW kernels (conv_raw_kernel F/T, conv_g_raw_kernel) -- the fast path for every layer geometry of the U-Net
+//    except k = 5: workgroup tile 128 (M) x 256 (N), 4 waves of 64 x 128 (128 accumulator registers, 2 waves/SIMD).
+//    The weight / P tile is gathered by LDS-DMA into a swizzled K-contiguous image; the ACTIVATION operand is staged
+//    as raw row windows (every element once) and the im2col overlap is resolved when fragments are read.  In-kernel
+//    stamps showed that global->LDS bytes per MFMA is what limits these kernels (LDS-DMA sustains ~5 B/clk per CU for
+//    these gathers): raw windows + a tile that is wide on the activation side cut those bytes by ~60 %.
+//  * IM2COL kernels (conv_f/t/g_kernel) -- 256 x 128 tile, both operands gathered element by element by LDS-DMA with
+//    per-lane source addresses (im2col, phase split, zero padding and the XOR swizzle all live in the address).  They
+//    serve k = 5, generic (k, s) and shapes whose windows do not fit, and stay covered by the tests (schedule bit 2).
+//
+// Common to both: operands reach LDS through buffer_load ... lds (no staging registers, no ds_write; out-of-range lanes
+// write 0.0, which implements conv padding, tile edges and K tails); (Leaky)ReLU in front of every conv is applied
+// branch-free on the MFMA fragments, so the in-place activations (model.py:80,82) and torch.cat (model.py:113) are
+// never materialised; phase order per slab is pinned with sched_barrier(0): gathers for slab s+1, then fragment reads
+// + MFMAs of slab s, then one __syncthreads() whose vmcnt(0) therefore sits behind the matrix work; double-buffered
+// LDS.  Work decomposition is a persistent stream-K split over (tile, slab) with a deterministic fixup kernel (below).
+// Each output element is accumulated in a fixed order: results are bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "phasegen.h"
