@@ -162,15 +162,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // ---------------------------------------------------------------------------------------------------------
 // data.py:39-47: [re; im] -> [log1p(|z|); angle(z)], 16 B of traffic per bin-frame.
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void polar_one(float re, float im, int use_exp, float& mag, float& ang) {
+    pg_complex_from_parts(re, im);
+    const float m = hypotf(re, im);
+    mag = use_exp ? log1pf(m) : m;
+    ang = atan2f(im, re);
+}
+
+// VEC = 4: 16-B loads/stores (inner % 4 == 0 and 16-B aligned planes); VEC = 1: any shape
+template <int VEC>
 __global__ __launch_bounds__(256) void polar_kernel(const float* __restrict__ in, float* __restrict__ out, long n_items, long inner, int use_exp) {
-    const long total = n_items * inner;
+    const long per = inner / VEC, total = n_items * per;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long it = e / inner, r = e - it * inner;
-        float re = in[it * 2 * inner + r], im = in[it * 2 * inner + inner + r];
-        pg_complex_from_parts(re, im);
-        const float mag = hypotf(re, im);
-        out[it * 2 * inner + r] = use_exp ? log1pf(mag) : mag;
-        out[it * 2 * inner + inner + r] = atan2f(im, re);
+        const long it = e / per, r = (e - it * per) * VEC;
+        const float* pre = in + it * 2 * inner + r;
+        float* pm = out + it * 2 * inner + r;
+        if (VEC == 4) {
+            const f32x4 re = *reinterpret_cast<const f32x4*>(pre), im = *reinterpret_cast<const f32x4*>(pre + inner);
+            f32x4 mg, an;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { float a, b; polar_one(re[k], im[k], use_exp, a, b); mg[k] = a; an[k] = b; }
+            *reinterpret_cast<f32x4*>(pm) = mg;
+            *reinterpret_cast<f32x4*>(pm + inner) = an;
+        } else {
+            float a, b;
+            polar_one(pre[0], pre[inner], use_exp, a, b);
+            pm[0] = a; pm[inner] = b;
+        }
     }
 }
 
@@ -235,7 +253,9 @@ extern "C" int pg_adam_step(const pg_adam_args* a, void* stream) {
 extern "C" int pg_polar(const pg_polar_args* a, void* stream) {
     if (!a || !a->in || !a->out) return pg_fail(PG_ERR_NULL, "polar: in, out required");
     if (a->n_items <= 0 || a->inner <= 0) return pg_fail(PG_ERR_SHAPE, "polar: non-positive size");
-    long blocks = (a->n_items * a->inner + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(polar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->in, a->out, (long)a->n_items, (long)a->inner, a->use_exp);
+    const bool vec = (a->inner & 3) == 0 && (((uintptr_t)a->in | (uintptr_t)a->out) & 15) == 0;
+    long blocks = (a->n_items * a->inner / (vec ? 4 : 1) + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    if (vec) hipLaunchKernelGGL(polar_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->in, a->out, (long)a->n_items, (long)a->inner, a->use_exp);
+    else hipLaunchKernelGGL(polar_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->in, a->out, (long)a->n_items, (long)a->inner, a->use_exp);
     return launch_ok("polar launch failed");
 }
