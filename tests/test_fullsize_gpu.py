@@ -1,0 +1,137 @@
+"""GPU parity at the FULL BASELINE sizes (C = 1024, frames 256, batch 64) through size-independent checks -- the oracle
+cannot run a batch-64 step in test time, so every conv layer of the U-Net is checked at its real geometry by
+
+  1. float64 spot values: a hundred output elements of fwd, dgrad and wgrad recomputed on the host DIRECTLY from the
+     inputs (dot products of up to 65 536 terms) -- exact parity on sampled positions, incl. the padded edges;
+  2. adjoint identities that tie the three passes together without any reference:
+        <conv(x, w), dy> == <x_act, dgrad(dy, w)> == <w, wgrad(x_act, dy)>      (to fp32 rounding);
+  3. the U-Net training step itself: two identical steps are bit-identical (fixed accumulation order everywhere) and a
+     step with every workgroup schedule forced (one tile per workgroup / im2col kernels under stream-K) agrees to rounding.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+C, L, B = 1024, 256, 64
+#          name  transposed Cin    Cout   k   s  p   Lin  act
+LAYERS = [("D0", False, C, 2 * C, 32, 2, 16, 256, 0), ("D1", False, 2 * C, 2 * C, 8, 1, 2, 129, 1),
+          ("D2", False, 2 * C, 2 * C, 8, 2, 1, 126, 1), ("D3", False, 2 * C, 4 * C, 4, 2, 1, 61, 1),
+          ("U3", True, 4 * C, 2 * C, 5, 2, 1, 30, 2), ("U2", True, 4 * C, 2 * C, 8, 2, 1, 61, 2),
+          ("U1", True, 4 * C, 2 * C, 8, 1, 2, 126, 2), ("U0", True, 4 * C, 2 * C, 32, 2, 16, 129, 2)]
+
+
+@pytest.fixture(params=[0, 1, 6], ids=["auto", "tile-per-wg", "im2col+stream-k"])
+def schedule(request):
+    from phasegen import ops
+    ops.set_conv_schedule(request.param)
+    yield request.param
+    ops.set_conv_schedule(0)
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_layer_at_full_size(layer, schedule):
+    from phasegen import ops
+    name, tr, Cin, Cout, k, s, p, Lin, act = layer
+    Lout = ops.convt_out_len(Lin, k, s, p) if tr else ops.conv_out_len(Lin, k, s, p)
+    g = torch.Generator(device="cuda").manual_seed(sum(map(ord, name)))
+    x = torch.randn(B, Cin, Lin, device="cuda", generator=g)
+    w = torch.randn((Cin, Cout, k) if tr else (Cout, Cin, k), device="cuda", generator=g) * 0.02
+    dy = torch.randn(B, Cout, Lout, device="cuda", generator=g)
+    y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
+    ops.conv_fwd(x, w, y, s, p, x_act=act, transposed=tr)
+    ops.conv_dgrad(dy, w, dx, s, p, transposed=tr)
+    ops.conv_wgrad(x, dy, dw, s, p, x_act=act, transposed=tr)
+    xa = torch.nn.functional.leaky_relu(x, 0.2) if act == 1 else (torch.relu(x) if act == 2 else x)
+    # --- adjoint identities (float64 reductions of the device tensors)
+    d1 = float((y.double() * dy.double()).sum())
+    d2 = float((xa.double() * dx.double()).sum())
+    d3 = float((w.double() * dw.double()).sum())
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(d1 - d2) < 2e-6 * scale and abs(d1 - d3) < 2e-6 * scale, (name, d1, d2, d3)
+    # --- float64 spot values straight from the inputs
+    rng = np.random.default_rng(7)
+    xh, wh, dyh = xa.cpu().double().numpy(), w.cpu().double().numpy(), dy.cpu().double().numpy()
+    yh, dxh, dwh = y.cpu().numpy(), dx.cpu().numpy(), dw.cpu().numpy()
+    ymax, dxmax, dwmax = np.abs(yh).max(), np.abs(dxh).max(), np.abs(dwh).max()
+    edge_t = [0, 1, Lout - 1, Lout // 2]
+    for n in range(48):                                         # y[b,o,t]
+        b, o = int(rng.integers(B)), int(rng.integers(Cout))
+        t = edge_t[n % 4] if n < 16 else int(rng.integers(Lout))
+        acc = 0.0
+        for j in range(k):
+            if tr:
+                if (t + p - j) % s:
+                    continue
+                i = (t + p - j) // s
+                if 0 <= i < Lin:
+                    acc += float(wh[:, o, j] @ xh[b, :, i])
+            else:
+                i = s * t + j - p
+                if 0 <= i < Lin:
+                    acc += float(wh[o, :, j] @ xh[b, :, i])
+        assert abs(yh[b, o, t] - acc) < 1e-4 * ymax, (name, "fwd", b, o, t, yh[b, o, t], acc)
+    for n in range(32):                                         # dx[b,c,i] (grad wrt the activated operand)
+        b, c = int(rng.integers(B)), int(rng.integers(Cin))
+        i = [0, Lin - 1][n % 2] if n < 8 else int(rng.integers(Lin))
+        acc = 0.0
+        for j in range(k):
+            if tr:
+                t = s * i + j - p
+                if 0 <= t < Lout:
+                    acc += float(wh[c, :, j] @ dyh[b, :, t])
+            else:
+                if (i + p - j) % s:
+                    continue
+                t = (i + p - j) // s
+                if 0 <= t < Lout:
+                    acc += float(wh[:, c, j] @ dyh[b, :, t])
+        assert abs(dxh[b, c, i] - acc) < 1e-4 * dxmax, (name, "dgrad", b, c, i, dxh[b, c, i], acc)
+    for n in range(24):                                         # dw: conv (o,c,j) / convT (c,o,j)
+        o, c = int(rng.integers(Cout)), int(rng.integers(Cin))
+        j = [0, k - 1][n % 2] if n < 8 else int(rng.integers(k))
+        acc = 0.0
+        if tr:
+            for i in range(Lin):
+                t = s * i + j - p
+                if 0 <= t < Lout:
+                    acc += float(xh[:, c, i] @ dyh[:, o, t])
+            got = dwh[c, o, j]
+        else:
+            for t in range(Lout):
+                i = s * t + j - p
+                if 0 <= i < Lin:
+                    acc += float(xh[:, c, i] @ dyh[:, o, t])
+            got = dwh[o, c, j]
+        assert abs(got - acc) < 1e-4 * dwmax, (name, "wgrad", o, c, j, got, acc)
+
+
+def test_full_size_step_is_reproducible_and_schedule_independent():
+    from phasegen import ops
+    from phasegen.model import UNetModel
+    from phasegen.trainer import Trainer
+    g = torch.Generator(device="cuda").manual_seed(3)
+    batch = torch.stack([torch.rand(B, C, L, device="cuda", generator=g) * 3,
+                         (torch.rand(B, C, L, device="cuda", generator=g) * 2 - 1) * torch.pi], dim=1).contiguous()
+    results = []
+    for mode in (0, 0, 1, 6):              # automatic twice, one tile per workgroup, im2col kernels under stream-K
+        torch.manual_seed(11)
+        m = UNetModel(C, 2 * C)
+        tr = Trainer(m)
+        ops.set_conv_schedule(mode)
+        losses = tr.step(batch).clone()
+        ops.set_conv_schedule(0)
+        results.append((losses, m.engine.arena.grad.clone()))
+        del tr, m
+        torch.cuda.empty_cache()
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])   # bit-reproducible
+    # Other schedules only change the ORDER of fp32 summation.  Losses agree to 1e-5; the gradient of a ReLU/LeakyReLU
+    # network is not continuous in such perturbations (a pre-activation within rounding of 0 flips its mask, and six
+    # batch-norms amplify it): measured 4e-3 of the gradient norm at this size, while every layer taken alone matches
+    # float64 spot values to 1e-4 under every schedule (test above).  Bound it loosely; a real indexing bug is O(1).
+    for losses, grad in results[2:]:
+        assert torch.allclose(losses, results[0][0], rtol=1e-5)
+        num = float((grad.double() - results[0][1].double()).norm())
+        den = float(results[0][1].double().norm())
+        assert num < 2e-2 * den, (num, den)
+    assert torch.isfinite(results[0][0]).all() and 0.5 < float(results[0][0][0]) < 10

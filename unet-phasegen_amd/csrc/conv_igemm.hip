@@ -497,17 +497,17 @@ constexpr int RTILE_A = RBM * BK;         // weight tile, same swizzled image as
 
 // ds_read_b32-based B fragments: lane (column block jb, column r, half h) needs k = 8h .. 8h+7 of the slab, i.e.
 // (channel qi, tap tau) = divmod(8h + i, TJ); the element lives at  qi*RS + bbase[jb] +/- tau.
+struct RawFrags { f32x4 a[2][2]; float b[4][8]; };
+
 template <int TJ, bool DESC>
-__device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
-                                             const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
+__device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
+                                               const int (&bbase)[4], float slopeA, float slopeB, RawFrags& f) {
     const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
     const float* ap = As + (wm * 64 + r) * BK;
-    f32x4 a[2][2];
-    float b[4][8];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+        for (int i = 0; i < 2; ++i) f.a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
     // lane part of the index: TJ == 16 -> one channel, taps 8h + i;  TJ <= 8 -> channels (8/TJ)*h + i/TJ, taps i % TJ
     const int lanepart = (TJ == 16) ? (DESC ? -8 * h : 8 * h) : (8 / TJ) * h * RS;
 #pragma unroll
@@ -516,7 +516,7 @@ __device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int qoff = (TJ == 16) ? 0 : (i / TJ) * RS, tau = (TJ == 16) ? i : (i % TJ);
-            b[jb][i] = bp[qoff + (DESC ? -tau : tau)];
+            f.b[jb][i] = bp[qoff + (DESC ? -tau : tau)];
         }
     }
     if (slopeA != 1.0f) {
@@ -525,21 +525,32 @@ __device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) a[i][c][v] = act_apply(a[i][c][v], slopeA);
+                for (int v = 0; v < 4; ++v) f.a[i][c][v] = act_apply(f.a[i][c][v], slopeA);
     }
     if (slopeB != 1.0f) {
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) b[jb][i] = act_apply(b[jb][i], slopeB);
+            for (int i = 0; i < 8; ++i) f.b[jb][i] = act_apply(f.b[jb][i], slopeB);
     }
+}
+
+__device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk], acc.c[i][j], 0, 0, 0);
+                acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk >> 2][kk & 3], f.b[j][kk], acc.c[i][j], 0, 0, 0);
+}
+
+template <int TJ, bool DESC>
+__device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
+                                             const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
+    RawFrags f;
+    raw_load_frags<TJ, DESC>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
+    raw_mfma(f, acc);
 }
 
 // TKIND false: F (conv fwd / convT dgrad, taps ascend with stride s between columns)
