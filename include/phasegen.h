@@ -48,6 +48,10 @@ typedef struct pg_conv_args {
     int32_t dx_mask; int32_t _pad1;
     float* dw;                       /* grad wrt w, same layout as w; OVERWRITTEN by *_wgrad (beta = 0:     */
                                      /*   optim.zero_grad(), train.py:41, is folded into the write)         */
+    int32_t y_act; int32_t y2_act;   /* *_fwd only: activation applied to the result as it is STORED (producers can */
+    float* y2;       int64_t y2_bs;  /*   hand consumers pre-activated tensors); y2 = optional second copy with its */
+                                     /*   own activation (the skip tensor is read as LeakyReLU by the next down conv */
+                                     /*   and as ReLU by the up path, model.py:80,82,113)                           */
     void* workspace; int64_t workspace_bytes; /* optional scratch (pg_workspace_bytes_conv()): lets tile counts   */
                                      /*   that quantise badly over the CUs be split evenly (stream-K);      */
                                      /*   contents are garbage between calls; NULL = always one tile per WG */
@@ -76,6 +80,8 @@ typedef struct pg_bn_args {
     const float* dy; int64_t dy_bs;      /* bwd: grad wrt y                                  */
     float* dx;       int64_t dx_bs;      /* bwd: grad wrt x                                  */
     float* dgamma; float* dbeta;         /* bwd: (C), overwritten                            */
+    int32_t y_act; int32_t y2_act;       /* fwd: activation applied as y is stored; optional second output y2 with  */
+    float* y2;       int64_t y2_bs;      /*   its own activation (same purpose as in pg_conv_args)                  */
 } pg_bn_args;
 int pg_bn_fwd(const pg_bn_args* a, void* stream);
 int pg_bn_bwd(const pg_bn_args* a, void* stream);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_the_header_layout():
     from phasegen import _lib
-    assert ctypes.sizeof(_lib.ConvArgs) == 8 * 4 + 8 + 8 + 4 + 4 + 8 + 4 * 16 + 8 + 8 + 8 + 8 + 16   # 184
+    assert ctypes.sizeof(_lib.ConvArgs) == 8 * 4 + 8 + 8 + 4 + 4 + 8 + 4 * 16 + 8 + 8 + 8 + 8 + 24 + 16   # 208
     assert ctypes.sizeof(_lib.AdamArgs) == 8 + 4 * 8 + 5 * 8 + 8
     assert ctypes.sizeof(_lib.LossArgs) == 16 + 4 * 8 + 8 + 8
 

@@ -18,6 +18,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--lib", default=None)
 ap.add_argument("--stamps", action="store_true")
+ap.add_argument("--act", type=int, default=2)
 a = ap.parse_args()
 if a.lib:
     from phasegen import _lib
@@ -39,9 +40,9 @@ for item in a.what:
     dy = torch.randn(B, Cout, Lout, device="cuda")
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
-    fn = {"fwd": lambda: ops.conv_fwd(x, w, y, s, p, x_act=2, transposed=tr),
+    fn = {"fwd": lambda: ops.conv_fwd(x, w, y, s, p, x_act=a.act, transposed=tr),
           "dgrad": lambda: ops.conv_dgrad(dy, w, dx, s, p, transposed=tr, ref=x, mask=2),
-          "wgrad": lambda: ops.conv_wgrad(x, dy, dw, s, p, x_act=2, transposed=tr)}[ps]
+          "wgrad": lambda: ops.conv_wgrad(x, dy, dw, s, p, x_act=a.act, transposed=tr)}[ps]
     fn(); torch.cuda.synchronize()
     if a.stamps:
         ops.set_conv_schedule(1)

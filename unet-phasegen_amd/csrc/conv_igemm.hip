@@ -59,17 +59,18 @@ struct IgemmParams {
     int LP; float inv_LP;            // G: frames of P and 1/LP
     int a_vec;                       // F: weight rows may be read as aligned float4
     int tilesM, tilesN;
+    float* y2; long y2_bs; float y_slope, y2_slope;   // F,T fwd: activation on store, optional second output
     float* ws;                       // stream-K partial-tile workspace: [grid][2][64][256] floats (or NULL)
     int nslab;                       // K slabs per tile
 };
 
-// Activations are applied branch-free as max(v,0) + slope*min(v,0): slope 1 = identity, 0.2 = LeakyReLU(0.2)
-// (model.py:80), 0 = ReLU (model.py:82).  A runtime switch here would make hipcc branch around every gathered
-// element and wait vmcnt(0) for each load in turn.
+// Activations are applied branch-free on the MFMA fragments as max(v, slope*v) -- exact for 0 <= slope <= 1:
+// slope 1 = identity, 0.2 = LeakyReLU(0.2) (model.py:80), 0 = ReLU (model.py:82).  A runtime switch per element would
+// make hipcc branch around every gathered value; callers test `slope != 1` once per slab (wave-uniform).
 __host__ __device__ __forceinline__ float act_slope(int act) {
     return act == PG_ACT_LEAKY02 ? 0.2f : (act == PG_ACT_RELU ? 0.0f : 1.0f);
 }
-__device__ __forceinline__ float act_apply(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+__device__ __forceinline__ float act_apply(float v, float slope) { return fmaxf(v, slope * v); }
 
 // Operand gathers go through buffer descriptors: a lane whose element is padding / out of the tile / past K gets
 // the offset OOB and the hardware returns 0.0 -- no exec-masked branch around the load, no 64-bit address math.
@@ -231,7 +232,8 @@ __device__ __forceinline__ void epilogue_f(const IgemmParams& p, const AccT<MB, 
                     const int off = m * p.Ly + t;
                     float v = acc.c[i][j][r];
                     if (ep.fused) v = ep(v, b * (int)p.add_bs + off, b * (int)p.ref_bs + off);
-                    yb[off] = v;
+                    yb[off] = act_apply(v, p.y_slope);
+                    if (p.y2) p.y2[(long)b * p.y2_bs + off] = act_apply(v, p.y2_slope);
                 }
             }
     }
@@ -258,7 +260,8 @@ __device__ __forceinline__ void epilogue_t(const IgemmParams& p, const AccT<MB, 
                     const int off = o * p.Ly + tau;
                     float v = acc.c[i][j][r];
                     if (ep.fused) v = ep(v, b * (int)p.add_bs + off, b * (int)p.ref_bs + off);
-                    yb[off] = v;
+                    yb[off] = act_apply(v, p.y_slope);
+                    if (p.y2) p.y2[(long)b * p.y2_bs + off] = act_apply(v, p.y2_slope);
                 }
             }
     }
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     constexpr int STG = RTILE_A + NQ * RS;            // floats per LDS stage
     static_assert(KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "raw-window kernels need 4/8/16/32 taps per channel");
     static_assert(!TKIND || KW % S == 0, "T raw kernel needs s | k");
-    __shared__ __attribute__((aligned(16))) float lds[2 * STG];
+    __shared__ __attribute__((aligned(16))) float lds[2 * ((NQ <= 2) ? 2 : 1) * STG];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
     const int kt = dma_kt(lane, wv);
@@ -666,15 +669,26 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     }
 
         PG_STAMP_DECL
-        RAW_ISSUE(lds, sb * BK)
+        // Two 16-deep slabs per barrier when the stage pair fits (SPB = 2): each LDS stage holds two half-stages that are
+        // gathered together and multiplied one after the other, halving the barrier (and gather-burst) rate.  Fragments
+        // are still loaded 16 deep, so the register budget is unchanged.  The second half is skipped when it lies past
+        // this segment's end (it belongs to the next workgroup's range, or past K where the gathers returned zeros).
+        constexpr int SPB = (NQ <= 2) ? 2 : 1;
+        constexpr int SSTG = SPB * STG;
+        static_assert(2 * SSTG * 4 <= 64 * 1024, "LDS budget");
+#pragma unroll
+        for (int hf = 0; hf < SPB; ++hf) RAW_ISSUE(lds + hf * STG, (sb + hf) * BK)
         __syncthreads();
-        for (int sl = sb; sl < se; ++sl) {
-            const int cur = (sl - sb) & 1;
+        for (int sl = sb; sl < se; sl += SPB) {
+            const int cur = ((sl - sb) / SPB) & 1;
             PG_STAMP(0)
-            RAW_ISSUE(lds + (cur ^ 1) * STG, (sl + 1) * BK)
+#pragma unroll
+            for (int hf = 0; hf < SPB; ++hf) RAW_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, (sl + SPB + hf) * BK)
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(1)
-            mma_slab_raw<TJ, TKIND>(lds + cur * STG, lds + cur * STG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
+            mma_slab_raw<TJ, TKIND>(lds + cur * SSTG, lds + cur * SSTG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
+            if (SPB == 2 && sl + 1 < se)
+                mma_slab_raw<TJ, TKIND>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(2)
             __syncthreads();
@@ -1049,6 +1063,7 @@ extern "C" int pg_conv1d_fwd(const pg_conv_args* a, void* stream) {
     if (int e = check_geom(a, false)) return e;
     if (!a->x || !a->w || !a->y) return pg_fail(PG_ERR_NULL, "conv1d_fwd: x, w, y required");
     IgemmParams p = {};
+    p.y_slope = act_slope(a->y_act); p.y2 = a->y2; p.y2_bs = a->y2_bs; p.y2_slope = act_slope(a->y2_act);
     p.x = a->x; p.x_bs = a->x_bs; p.w = a->w; p.y = a->y; p.y_bs = a->y_bs;
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.Ly = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
     p.act_x = a->x_act;
@@ -1062,6 +1077,7 @@ extern "C" int pg_convt1d_dgrad(const pg_conv_args* a, void* stream) {
     if (int e = check_geom(a, true)) return e;
     if (!a->dy || !a->w || !a->dx) return pg_fail(PG_ERR_NULL, "convt1d_dgrad: dy, w, dx required");
     IgemmParams p = {};
+    p.y_slope = 1.0f; p.y2_slope = 1.0f;
     p.x = a->dy; p.x_bs = a->dy_bs; p.w = a->w; p.y = a->dx; p.y_bs = a->dx_bs;
     p.add = a->dx_add; p.add_bs = a->dx_add_bs; p.ref = a->dx_ref; p.ref_bs = a->dx_ref_bs;
     p.mask_mode = a->dx_ref ? a->dx_mask : 0;
@@ -1086,6 +1102,7 @@ extern "C" int pg_convt1d_fwd(const pg_conv_args* a, void* stream) {
     if (int e = check_geom(a, true)) return e;
     if (!a->x || !a->w || !a->y) return pg_fail(PG_ERR_NULL, "convt1d_fwd: x, w, y required");
     IgemmParams p = {};
+    p.y_slope = act_slope(a->y_act); p.y2 = a->y2; p.y2_bs = a->y2_bs; p.y2_slope = act_slope(a->y2_act);
     p.x = a->x; p.x_bs = a->x_bs; p.w = a->w; p.y = a->y; p.y_bs = a->y_bs;
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.Ly = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
     p.act_x = a->x_act;
@@ -1098,6 +1115,7 @@ extern "C" int pg_conv1d_dgrad(const pg_conv_args* a, void* stream) {
     if (int e = check_geom(a, false)) return e;
     if (!a->dy || !a->w || !a->dx) return pg_fail(PG_ERR_NULL, "conv1d_dgrad: dy, w, dx required");
     IgemmParams p = {};
+    p.y_slope = 1.0f; p.y2_slope = 1.0f;
     p.x = a->dy; p.x_bs = a->dy_bs; p.w = a->w; p.y = a->dx; p.y_bs = a->dx_bs;
     p.add = a->dx_add; p.add_bs = a->dx_add_bs; p.ref = a->dx_ref; p.ref_bs = a->dx_ref_bs;
     p.mask_mode = a->dx_ref ? a->dx_mask : 0;

@@ -15,6 +15,8 @@ namespace {
 // model.py:81,83 (nn.BatchNorm on (B, C, L)): mean / biased var over (B, L), eps inside the sqrt,
 // running_var gets the unbiased variance, momentum 0.1.
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bn_slope(int act) { return act == PG_ACT_LEAKY02 ? 0.2f : (act == PG_ACT_RELU ? 0.0f : 1.0f); }
+
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const pg_bn_args a) {
     __shared__ float scratch[16];
     const int c = blockIdx.x, n = a.B * a.L;
@@ -35,9 +37,13 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const pg_bn_args a) {
     const float invstd = 1.0f / sqrtf(var + a.eps);
     const float g = a.gamma[c], be = a.beta[c];
     float* yc = a.y + (long)c * a.L;
+    float* y2c = a.y2 ? a.y2 + (long)c * a.L : nullptr;
+    const float s1 = bn_slope(a.y_act), s2 = bn_slope(a.y2_act);
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const int b = e / a.L, l = e - b * a.L;
-        yc[(long)b * a.y_bs + l] = (xc[(long)b * a.x_bs + l] - mean) * invstd * g + be;
+        const float v = (xc[(long)b * a.x_bs + l] - mean) * invstd * g + be;
+        yc[(long)b * a.y_bs + l] = fmaxf(v, s1 * v);            // slope 1 = identity, 0.2 = LeakyReLU, 0 = ReLU
+        if (y2c) y2c[(long)b * a.y2_bs + l] = fmaxf(v, s2 * v);
     }
     if (threadIdx.x == 0) {
         a.save_mean[c] = mean;

@@ -26,7 +26,8 @@ class ConvArgs(C.Structure):
                 ("dx_add", C.c_void_p), ("dx_add_bs", C.c_int64),
                 ("dx_ref", C.c_void_p), ("dx_ref_bs", C.c_int64),
                 ("dx_mask", C.c_int32), ("_pad1", C.c_int32),
-                ("dw", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("dw", C.c_void_p), ("y_act", C.c_int32), ("y2_act", C.c_int32), ("y2", C.c_void_p), ("y2_bs", C.c_int64),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class BnArgs(C.Structure):
@@ -36,7 +37,8 @@ class BnArgs(C.Structure):
                 ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("dy", C.c_void_p), ("dy_bs", C.c_int64), ("dx", C.c_void_p), ("dx_bs", C.c_int64),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("y_act", C.c_int32), ("y2_act", C.c_int32), ("y2", C.c_void_p), ("y2_bs", C.c_int64)]
 
 
 class LossArgs(C.Structure):

@@ -113,8 +113,9 @@ def _geom(transposed, w, k=None):
     return Cin, Cout, kk
 
 
-def conv_fwd(x, w, y, stride, pad, x_act=ACT_NONE, transposed=False):
-    """y = conv(act(x), w) (nn.Conv1d, model.py:77) or conv_transpose (model.py:88) -- writes into ``y``."""
+def conv_fwd(x, w, y, stride, pad, x_act=ACT_NONE, transposed=False, y_act=ACT_NONE, y2=None, y2_act=ACT_NONE):
+    """y = y_act(conv(x_act(x), w)) (nn.Conv1d, model.py:77) or conv_transpose (model.py:88) -- writes into ``y``;
+    optionally a second copy ``y2 = y2_act(conv(...))`` (pre-activated tensors for the consumers)."""
     Cin, Cout, k = _geom(transposed, w)
     B, _, Lin = x.shape
     a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, x.device)
@@ -123,7 +124,11 @@ def conv_fwd(x, w, y, stride, pad, x_act=ACT_NONE, transposed=False):
     a.x, a.x_bs = _act3(x, "x")
     a.y, a.y_bs = _act3(y, "y")
     a.w = _dense(w, "w")
-    a.x_act = x_act
+    a.x_act, a.y_act, a.y2_act = x_act, y_act, y2_act
+    if y2 is not None:
+        if y2.shape != y.shape:
+            raise ValueError("conv_fwd: y2 must have y's shape")
+        a.y2, a.y2_bs = _act3(y2, "y2")
     lib = _lib.load()
     fn = lib.pg_convt1d_fwd if transposed else lib.pg_conv1d_fwd
     _lib.check(fn(C.byref(a), _stream()), "convt1d_fwd" if transposed else "conv1d_fwd")
@@ -172,8 +177,12 @@ def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False):
     return dw
 
 
-def bn_fwd(x, y, gamma, beta, save_mean, save_invstd, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+def bn_fwd(x, y, gamma, beta, save_mean, save_invstd, running_mean=None, running_var=None, eps=1e-5, momentum=0.1,
+           y_act=ACT_NONE, y2=None, y2_act=ACT_NONE):
     a = _lib.BnArgs()
+    a.y_act, a.y2_act = y_act, y2_act
+    if y2 is not None:
+        a.y2, a.y2_bs = _act3(y2, "y2")
     a.B, a.C, a.L = x.shape
     a.eps, a.momentum = eps, momentum
     a.x, a.x_bs = _act3(x, "x")

@@ -10,9 +10,12 @@ MI355X-first layout decisions:
   * ONE flat fp32 arena for all 20 parameters (and a twin for gradients): Adam is a single streaming launch, the
     data-parallel all-reduce works on contiguous buckets of the same arena, a checkpoint is one copy.
   * torch.cat is never executed: each concat is one (B, 4C, L') buffer whose halves are written in place by the
-    producing BatchNorm / conv (batch-stride-aware kernels).  The in-place LeakyReLU of model.py:80 is not
-    executed either: buffers hold PRE-activation values and every consumer applies leaky / relu as it loads
-    (relu(leaky(x)) == relu(x), so the skip half needs no second copy).
+    producing BatchNorm / conv (batch-stride-aware kernels).  The in-place (Leaky)ReLUs of model.py:80,82 are not
+    separate passes either: PRODUCERS store pre-activated tensors -- a skip tensor h is written twice, as
+    LeakyReLU(h) for the next down conv and as ReLU(h) (== ReLU(LeakyReLU(h))) into the concat buffer the up path
+    reads -- so every conv of the network loads its operand with the identity (the fused activation-on-load of the
+    C ABI costs ~6 % of MFMA issue slots in the matrix loop; measured).  BatchNorm backward uses the raw conv outputs,
+    activation-derivative masks use the sign of the stored activated tensors (sign is preserved).
   * backward mirrors it: dgrad epilogues add the skip gradient and multiply by the activation derivative, wgrad
     overwrites the gradient arena (zero_grad folded in).
 """
@@ -137,7 +140,9 @@ class UNetEngine:
 
             def z(*s):
                 return torch.empty(*s, device=dev, dtype=torch.float32)
+            # cat*: [relu(skip) | relu(up)]; l0/l1/l2: leaky(a0/h1/h2); d3: relu(d3); c*/r*: raw conv outputs (for BN bwd)
             f = dict(cat0=z(B, 4 * C, L1), cat1=z(B, 4 * C, L2), cat2=z(B, 4 * C, L3), d3=z(B, 4 * C, L4),
+                     l0=z(B, 2 * C, L1), l1=z(B, 2 * C, L2), l2=z(B, 2 * C, L3),
                      c1=z(B, 2 * C, L2), c2=z(B, 2 * C, L3), r3=z(B, 2 * C, L3), r2=z(B, 2 * C, L2),
                      r1=z(B, 2 * C, L1), r0=z(B, 2 * C, L), out=z(B, 2 * C, L))
             self.plans[key] = dict(fwd=f, bwd=None, L=(L, L1, L2, L3, L4))
@@ -157,18 +162,18 @@ class UNetEngine:
         return plan["bwd"]
 
     # -- helpers -----------------------------------------------------------------------------------------------
-    def _conv(self, name, x, y, act):
+    def _conv(self, name, x, y, y_act=ACT_NONE, y2=None, y2_act=ACT_NONE):
         key, kind, s, p = LAYERS[name]
         with ops.timed(name + ".fwd"):
-            ops.conv_fwd(x, self.arena.p(key), y, s, p, x_act=act, transposed=(kind == "t"))
+            ops.conv_fwd(x, self.arena.p(key), y, s, p, transposed=(kind == "t"), y_act=y_act, y2=y2, y2_act=y2_act)
 
-    def _bn(self, name, x, y, update_stats):
+    def _bn(self, name, x, y, update_stats, y_act=ACT_NONE, y2=None, y2_act=ACT_NONE):
         key = BN_OF[name]
         a = self.arena
         sm, si = self.bn_save[name]
         rm = a.buffers[key + ".running_mean"] if update_stats else None
         rv = a.buffers[key + ".running_var"] if update_stats else None
-        ops.bn_fwd(x, y, a.p(key + ".weight"), a.p(key + ".bias"), sm, si, rm, rv)
+        ops.bn_fwd(x, y, a.p(key + ".weight"), a.p(key + ".bias"), sm, si, rm, rv, y_act=y_act, y2=y2, y2_act=y2_act)
         if update_stats:
             a.buffers[key + ".num_batches_tracked"] += 1
 
@@ -184,19 +189,19 @@ class UNetEngine:
         plan = self.plan(B, L)
         f = plan["fwd"]
         h = 2 * C
-        self._conv("D0", x, f["cat0"][:, :h], ACT_NONE)
-        self._conv("D1", f["cat0"][:, :h], f["c1"], ACT_LEAKY)
-        self._bn("D1", f["c1"], f["cat1"][:, :h], update_stats)
-        self._conv("D2", f["cat1"][:, :h], f["c2"], ACT_LEAKY)
-        self._bn("D2", f["c2"], f["cat2"][:, :h], update_stats)
-        self._conv("D3", f["cat2"][:, :h], f["d3"], ACT_LEAKY)
-        self._conv("U3", f["d3"], f["r3"], ACT_RELU)
-        self._bn("U3", f["r3"], f["cat2"][:, h:], update_stats)
-        self._conv("U2", f["cat2"], f["r2"], ACT_RELU)
-        self._bn("U2", f["r2"], f["cat1"][:, h:], update_stats)
-        self._conv("U1", f["cat1"], f["r1"], ACT_RELU)
-        self._bn("U1", f["r1"], f["cat0"][:, h:], update_stats)
-        self._conv("U0", f["cat0"], f["r0"], ACT_RELU)
+        self._conv("D0", x, f["l0"], ACT_LEAKY, f["cat0"][:, :h], ACT_RELU)         # a0 -> leaky(a0), relu(a0)
+        self._conv("D1", f["l0"], f["c1"])
+        self._bn("D1", f["c1"], f["l1"], update_stats, ACT_LEAKY, f["cat1"][:, :h], ACT_RELU)   # h1
+        self._conv("D2", f["l1"], f["c2"])
+        self._bn("D2", f["c2"], f["l2"], update_stats, ACT_LEAKY, f["cat2"][:, :h], ACT_RELU)   # h2
+        self._conv("D3", f["l2"], f["d3"], ACT_RELU)                                  # relu(d3)
+        self._conv("U3", f["d3"], f["r3"])
+        self._bn("U3", f["r3"], f["cat2"][:, h:], update_stats, ACT_RELU)             # relu(u3)
+        self._conv("U2", f["cat2"], f["r2"])
+        self._bn("U2", f["r2"], f["cat1"][:, h:], update_stats, ACT_RELU)
+        self._conv("U1", f["cat1"], f["r1"])
+        self._bn("U1", f["r1"], f["cat0"][:, h:], update_stats, ACT_RELU)
+        self._conv("U0", f["cat0"], f["r0"])
         self._bn("U0", f["r0"], f["out"], update_stats)
         self.cur = (plan, x)
         return f["out"]
@@ -235,27 +240,28 @@ class UNetEngine:
             if on_grads_ready is not None:
                 on_grads_ready(name)
 
-        # up path, outermost first
+        # up path, outermost first.  Operands are the stored activated tensors (identity on load); the mask relu'(.) is
+        # taken from their sign.
         for name, cat, raw, gin, g_raw, g_cat in (("U0", "cat0", "r0", g_out, "g_r0", "g_cat0"),
                                                   ("U1", "cat1", "r1", g["g_cat0"][:, h:], "g_r1", "g_cat1"),
                                                   ("U2", "cat2", "r2", g["g_cat1"][:, h:], "g_r2", "g_cat2"),
                                                   ("U3", "d3", "r3", g["g_cat2"][:, h:], "g_r3", "g_d3")):
             bn_bwd(name, f[raw], gin, g[g_raw])
-            wgrad(name, f[cat], g[g_raw], ACT_RELU)
+            wgrad(name, f[cat], g[g_raw], ACT_NONE)
             ready(name)
             dgrad(name, g[g_raw], g[g_cat], ref=f[cat], mask=ACT_RELU)
-        # down path, innermost first; each dgrad adds the skip gradient and applies leaky'
-        wgrad("D3", f["cat2"][:, :h], g["g_d3"], ACT_LEAKY)
+        # down path, innermost first; each dgrad adds the skip gradient and applies leaky' (sign of the stored leaky(h))
+        wgrad("D3", f["l2"], g["g_d3"], ACT_NONE)
         ready("D3")
-        dgrad("D3", g["g_d3"], g["g_cat2"][:, :h], add=g["g_cat2"][:, :h], ref=f["cat2"][:, :h], mask=ACT_LEAKY)
+        dgrad("D3", g["g_d3"], g["g_cat2"][:, :h], add=g["g_cat2"][:, :h], ref=f["l2"], mask=ACT_LEAKY)
         bn_bwd("D2", f["c2"], g["g_cat2"][:, :h], g["g_c2"])
-        wgrad("D2", f["cat1"][:, :h], g["g_c2"], ACT_LEAKY)
+        wgrad("D2", f["l1"], g["g_c2"], ACT_NONE)
         ready("D2")
-        dgrad("D2", g["g_c2"], g["g_cat1"][:, :h], add=g["g_cat1"][:, :h], ref=f["cat1"][:, :h], mask=ACT_LEAKY)
+        dgrad("D2", g["g_c2"], g["g_cat1"][:, :h], add=g["g_cat1"][:, :h], ref=f["l1"], mask=ACT_LEAKY)
         bn_bwd("D1", f["c1"], g["g_cat1"][:, :h], g["g_c1"])
-        wgrad("D1", f["cat0"][:, :h], g["g_c1"], ACT_LEAKY)
+        wgrad("D1", f["l0"], g["g_c1"], ACT_NONE)
         ready("D1")
-        dgrad("D1", g["g_c1"], g["g_cat0"][:, :h], add=g["g_cat0"][:, :h], ref=f["cat0"][:, :h], mask=ACT_LEAKY)
+        dgrad("D1", g["g_c1"], g["g_cat0"][:, :h], add=g["g_cat0"][:, :h], ref=f["l0"], mask=ACT_LEAKY)
         wgrad("D0", x0, g["g_cat0"][:, :h], ACT_NONE)      # network input needs no dgrad
         ready("D0")
 
@@ -266,10 +272,12 @@ class UNetEngine:
         return keys
 
     def intermediates(self):
-        """Forward tensors by oracle name (test hook)."""
+        """Forward tensors by oracle name (test hook).  Raw conv outputs as they are; the tensors the reference would
+        hold pre-activation are stored activated here: ``leaky:<name>`` / ``relu:<name>``."""
         plan, _ = self.cur
         f = plan["fwd"]
         h = 2 * self.C
-        return dict(a0=f["cat0"][:, :h], c1=f["c1"], h1=f["cat1"][:, :h], c2=f["c2"], h2=f["cat2"][:, :h], d3=f["d3"],
-                    r3=f["r3"], u3=f["cat2"][:, h:], r2=f["r2"], u2=f["cat1"][:, h:], r1=f["r1"], u1=f["cat0"][:, h:],
-                    r0=f["r0"], out=f["out"])
+        return {"leaky:a0": f["l0"], "relu:a0": f["cat0"][:, :h], "c1": f["c1"], "leaky:h1": f["l1"], "relu:h1": f["cat1"][:, :h],
+                "c2": f["c2"], "leaky:h2": f["l2"], "relu:h2": f["cat2"][:, :h], "relu:d3": f["d3"], "r3": f["r3"],
+                "relu:u3": f["cat2"][:, h:], "r2": f["r2"], "relu:u2": f["cat1"][:, h:], "r1": f["r1"],
+                "relu:u1": f["cat0"][:, h:], "r0": f["r0"], "out": f["out"]}
