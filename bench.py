@@ -11,7 +11,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
                batch 64) -- algorithmic FLOPs per launch / its average launch duration measured here with HIP events
                on the launch stream, against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
   cpu_baseline the oracle (CPU restatement of the reference, oracle/unet_ref.py) doing the SAME training step on the
-               host cores on a bounded sample (batch 4 of the same C=1024, L=256 model); rank 0, N = 1 only.
+               host cores on a bounded sample (batch 16 of the same C=1024, L=256 model); rank 0, N = 1 only.
   kernels      per-layer conv timings (ms, TFLOP/s) for DESIGN.md's table.
 """
 import argparse
@@ -65,13 +65,13 @@ def pmc_traffic(kernel_substr):
 
 
 def cpu_baseline(C, L, max_threads=None):
-    """One oracle training step at batch 4 on the host (bounded sample: ~10-20 s of CPU work on 16 threads)."""
+    """One oracle training step at batch 16 on the host (bounded sample: ~15 s of CPU work on 16 threads)."""
     import torch
     from oracle import unet_ref
     from phasegen import detgen
     threads = max_threads or host_threads()
     torch.set_num_threads(threads)
-    B = 4
+    B = 16
     shapes = detgen.conv_shapes(C)
     g = torch.Generator().manual_seed(0)
     p = {}
