@@ -57,7 +57,8 @@ typedef struct pg_conv_args {
                                      /*   contents are garbage between calls; NULL = always one tile per WG */
 } pg_conv_args;
 int64_t pg_workspace_bytes_conv(void);
-int pg_conv_set_schedule(int mode);  /* test hook: 0 auto, 1 one tile per workgroup, 2 force stream-K       */
+int pg_conv_set_schedule(int mode);  /* test hook: bits 0-1: 0 auto, 1 one tile per workgroup, 2 force stream-K; bit 2: no raw-window kernels */
+int pg_conv_set_oversubscribe(int factor); /* stream-K grid = factor x resident slots (1..8); > 1 when other kernels (RCCL) share the chip */
 
 /* nn.Conv1d forward / backward (model.py:77-78; autograd of train.py:61) */
 int pg_conv1d_fwd(const pg_conv_args* a, void* stream);

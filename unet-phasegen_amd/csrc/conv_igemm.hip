@@ -917,8 +917,13 @@ hipError_t launch_kind(Kind kind, const IgemmParams& p, int grid, hipStream_t st
 }
 
 constexpr int WG_PER_CU = 2;                    // <= 256 VGPR+AGPR per lane -> 2 waves per SIMD; 48 KB LDS per workgroup
-constexpr int MAX_STREAMK_WG = 768;             // bound on the persistent grid (sizes the caller's workspace)
+constexpr int MAX_STREAMK_WG = 2048;            // bound on the persistent grid (sizes the caller's workspace)
 constexpr long WS_PER_WG = 2L * ACC_REGS * NT * 4;   // two partial tiles of 256x128 fp32 per workgroup
+
+// schedule knobs (process-wide; set through pg_conv_set_schedule / pg_conv_set_oversubscribe)
+int g_force_mode = 0;   // work split: 0 automatic, 1 one tile per workgroup, 2 force stream-K
+int g_force_raw = 0;    // 1 = never use the raw-window kernels (exercise the im2col kernels)
+int g_oversub = 4;      // stream-K grid = up to g_oversub x resident workgroup slots
 
 // Number of CUs of the current device (immutable per device; cached).
 int cu_count() {
@@ -932,24 +937,27 @@ int cu_count() {
     return cached[dev];
 }
 
-// Grid policy.  tiles workgroups (one whole tile each) unless the tile count quantises badly over the CUs and the
-// caller supplied a workspace: then a persistent grid of all resident workgroup slots with the (tile, slab) space
-// split evenly (stream-K) plus the fixup launch.  mode: 0 auto, 1 force plain, 2 force stream-K (tests).
+// Grid policy.  Default: a persistent stream-K grid of up to g_oversub (4) x the resident workgroup slots, each
+// workgroup owning an equal contiguous range of the (tile, slab) space, plus the fixup launch.  Measured on MI355X
+// (tools/contention.py): the oversubscribed split costs nothing on a free chip, removes tile-count quantisation, and --
+// what matters for data-parallel training, where RCCL's collective kernels hold part of the chip during backward --
+// degrades gracefully when slots are taken (16 of 512 slots held: 1x split 33 -> 58 ms, one-tile-per-workgroup 32 -> 43 ms,
+// 4x split 33 -> 37 ms).  Small problems (less than 8 slabs per resident slot, or no workspace) run one tile per
+// workgroup.  mode: 0 auto, 1 force one tile per workgroup, 2 force stream-K (tests).
 int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mode) {
-    const int cus = cu_count();
-    long G = (long)cus * WG_PER_CU;
-    if (G > MAX_STREAMK_WG) G = MAX_STREAMK_WG;
-    if (G > tiles * (long)nslab) G = tiles * (long)nslab;
-    const bool can = p.ws && ws_bytes >= G * WS_PER_WG && tiles * (long)nslab < 0x7fffffffL;
+    const long total = tiles * (long)nslab;
+    const long slots = (long)cu_count() * WG_PER_CU;
+    long mult = total / (256 * slots);               // whole multiples of the slot count only (a ragged second wave is
+    if (mult > g_oversub) mult = g_oversub;          // worse than none), and >= 256 slabs per workgroup so that partial-
+    if (mult < 1) mult = 1;                          // tile traffic stays negligible
+    long G = slots * mult;
+    if (G > MAX_STREAMK_WG) G = (MAX_STREAMK_WG / slots) * slots;
+    if (G > total) G = total;
+    const bool can = p.ws && ws_bytes >= G * WS_PER_WG && total < 0x7fffffffL;
     if (mode == 1 || !can) return (int)tiles;
     if (mode == 2) return (int)G;
-    const long rounds = (tiles + cus - 1) / cus;                 // whole tiles per CU, worst CU
-    const double balance = (double)tiles / (double)(rounds * cus);
-    return balance < 0.93 ? (int)G : (int)tiles;
+    return total >= slots * 8 ? (int)G : (int)tiles;
 }
-
-int g_force_mode = 0;   // test hook, set through pg_conv_set_schedule(): work split
-int g_force_raw = 0;    // test hook: 1 = never use the raw-window kernels (exercise the im2col F/T kernels)
 
 // raw-window kernels: supported (k, s) pairs and the window-length bound
 bool raw_supported(Kind kind, const IgemmParams& p) {
@@ -1160,5 +1168,15 @@ extern "C" int pg_conv_set_schedule(int mode) {
     if (mode < 0 || mode > 7 || (mode & 3) == 3) return pg_fail(PG_ERR_SHAPE, "conv_set_schedule: bad mode");
     g_force_mode = mode & 3;
     g_force_raw = (mode >> 2) & 1;
+    return PG_OK;
+}
+
+// Stream-K launches one workgroup per resident slot and gives each the same amount of work.  When other kernels hold part
+// of the chip (RCCL's collective kernels during data-parallel backward), the workgroups that do not fit run as a second
+// wave and the launch takes up to twice as long.  factor > 1 splits the work over factor x more, proportionally shorter
+// workgroups, which bounds that tail at 1/factor of a workgroup's duration (at the price of more partial tiles).
+extern "C" int pg_conv_set_oversubscribe(int factor) {
+    if (factor < 1 || factor > 8) return pg_fail(PG_ERR_SHAPE, "conv_set_oversubscribe: factor must be 1..8");
+    g_oversub = factor;
     return PG_OK;
 }

@@ -95,6 +95,11 @@ def set_conv_schedule(mode):
     _lib.check(_lib.load().pg_conv_set_schedule(mode), "conv_set_schedule")
 
 
+def set_conv_oversubscribe(factor):
+    """Stream-K grid = factor x resident workgroup slots.  Use > 1 when other kernels (RCCL collectives) share the chip."""
+    _lib.check(_lib.load().pg_conv_set_oversubscribe(factor), "conv_set_oversubscribe")
+
+
 def _conv_args(transposed, B, Cin, Cout, Lin, k, s, p, device=None):
     a = _lib.ConvArgs()
     a.B, a.Cin, a.Cout, a.Lin, a.k, a.stride, a.pad = B, Cin, Cout, Lin, k, s, p
