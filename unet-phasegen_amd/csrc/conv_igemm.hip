@@ -494,7 +494,7 @@ __global__ __launch_bounds__(NT, 2) void conv_g_kernel(const IgemmParams p) {
 // everything else (k = 5, generic) stays on the im2col kernels.
 // ================================================================================================================
 constexpr int RBM = 128, RBN = 256;       // raw-window workgroup tile
-constexpr int RS = 768;                   // floats reserved per channel window
+constexpr int RS2 = 768, RS1 = 384;       // floats reserved per channel window for column stride 2 / 1
 constexpr int RG = 16;                    // gap between the windows of consecutive samples inside a tile
 constexpr int RTILE_A = RBM * BK;         // weight tile, same swizzled image as above (8 KB)
 
@@ -502,7 +502,7 @@ constexpr int RTILE_A = RBM * BK;         // weight tile, same swizzled image as
 // (channel qi, tap tau) = divmod(8h + i, TJ); the element lives at  qi*RS + bbase[jb] +/- tau.
 struct RawFrags { f32x4 a[2][2]; float b[4][8]; };
 
-template <int TJ, bool DESC>
+template <int TJ, bool DESC, int RS>
 __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
                                                const int (&bbase)[4], float slopeA, float slopeB, RawFrags& f) {
     const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
@@ -548,11 +548,11 @@ __device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
                 acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk >> 2][kk & 3], f.b[j][kk], acc.c[i][j], 0, 0, 0);
 }
 
-template <int TJ, bool DESC>
+template <int TJ, bool DESC, int RS>
 __device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
                                              const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
     RawFrags f;
-    raw_load_frags<TJ, DESC>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
+    raw_load_frags<TJ, DESC, RS>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
     raw_mfma(f, acc);
 }
 
@@ -563,10 +563,13 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
     constexpr int TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ;
     constexpr int SC = TKIND ? 1 : S;                 // window positions per column step
+    constexpr int RS = SC == 1 ? RS1 : RS2;           // floats reserved per channel window
+    constexpr int NPC = (RS + NT - 1) / NT;           // gather pieces per thread and window
     constexpr int STG = RTILE_A + NQ * RS;            // floats per LDS stage
+    constexpr int SPB = (4 * STG * 4 <= 64 * 1024) ? 2 : 1;   // slabs per barrier (two when both stages still fit 64 KB)
     static_assert(KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "raw-window kernels need 4/8/16/32 taps per channel");
     static_assert(!TKIND || KW % S == 0, "T raw kernel needs s | k");
-    __shared__ __attribute__((aligned(16))) float lds[2 * ((NQ <= 2) ? 2 : 1) * STG];
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPB * STG];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
     const int kt = dma_kt(lane, wv);
@@ -609,9 +612,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             }
         }
         // --- window gather constants: thread owns window positions v = tid + 256 e --------------------------------
-        int posb[3], rowb[3];
+        int posb[NPC], rowb[NPC];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
+        for (int e = 0; e < NPC; ++e) {
             const int v = tid + 256 * e;
             int k = 0;                                            // segment (sample) this window position belongs to
             while (k + 1 < nseg && SC * ((k + 1) * Lcol - t0) + RG * (k + 1) <= v) ++k;
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                               \
             const int qq = q0 + qi;                                                                       \
             const int qo = (kok && qq < p.Q) ? qq * p.Lx : -NEVER;                                        \
-            _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                               \
+            _Pragma("unroll") for (int e = 0; e < NPC; ++e) {                                             \
                 if (e * 256 + wv * 64 < rlen) {                                                           \
                     const int ps = posb[e] + (TKIND ? -tau0 : tau0);                                      \
                     const bool ok = (unsigned)ps < (unsigned)p.Lx && qo >= 0;                             \
@@ -673,7 +676,6 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         // gathered together and multiplied one after the other, halving the barrier (and gather-burst) rate.  Fragments
         // are still loaded 16 deep, so the register budget is unchanged.  The second half is skipped when it lies past
         // this segment's end (it belongs to the next workgroup's range, or past K where the gathers returned zeros).
-        constexpr int SPB = (NQ <= 2) ? 2 : 1;
         constexpr int SSTG = SPB * STG;
         static_assert(2 * SSTG * 4 <= 64 * 1024, "LDS budget");
 #pragma unroll
@@ -686,9 +688,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             for (int hf = 0; hf < SPB; ++hf) RAW_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, (sl + SPB + hf) * BK)
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(1)
-            mma_slab_raw<TJ, TKIND>(lds + cur * SSTG, lds + cur * SSTG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
+            mma_slab_raw<TJ, TKIND, RS>(lds + cur * SSTG, lds + cur * SSTG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
             if (SPB == 2 && sl + 1 < se)
-                mma_slab_raw<TJ, TKIND>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
+                mma_slab_raw<TJ, TKIND, RS>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(2)
             __syncthreads();
@@ -975,7 +977,7 @@ bool raw_supported(Kind kind, const IgemmParams& p) {
     }
     const int tj = kwp < 16 ? kwp : 16;
     const int nseg_max = (lcol - 1 + RBN - 1) / lcol + 1;
-    return sc * (RBN - 1) + tj + RG * (nseg_max - 1) + (kind == KIND_T ? tj : 0) <= RS;
+    return sc * (RBN - 1) + tj + RG * (nseg_max - 1) + (kind == KIND_T ? tj : 0) <= (sc == 1 ? RS1 : RS2);
 }
 
 template <int KW, int S, bool TK>
