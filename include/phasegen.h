@@ -117,6 +117,10 @@ typedef struct pg_stft_args {
     const float* y; float* out;
 } pg_stft_args;
 int pg_stft(const pg_stft_args* a, void* stream);
+/* Transform schedule of pg_stft / pg_istft: 0 (default) = 4 frames per workgroup, real FFT through an n_fft/2-point radix-4
+ * transform (n_fft <= 2048; longer transforms always take the other path); 1 = one frame per workgroup, full-length radix-2
+ * transform.  Both follow the same framing; they differ in fp32 rounding only.  Process-wide; for tests and measurements. */
+int pg_stft_set_mode(int32_t single_frame);
 /* The integer framing map alone (bit-exact contract): idx[t, k] = sample index of tap k of frame t. */
 int pg_stft_frame_index(int32_t n_samples, int32_t n_fft, int32_t hop, int32_t n_frames, int32_t* idx, void* stream);
 

@@ -94,6 +94,31 @@ def test_istft_vs_oracle(bins, frames, hop, nsig):
             assert relmax(y[i], w) < 2e-5
 
 
+@pytest.mark.parametrize("n,n_fft,hop,nsig", [(66100, 2048, 512, 3), (10007, 512, 128, 2), (3001, 256, 50, 1), (97, 32, 8, 5)])
+def test_batched_and_single_frame_transforms_agree(n, n_fft, hop, nsig):
+    """The two transform schedules (4 frames per workgroup through the half-length radix-4 real FFT / one frame per
+    workgroup, full-length radix-2) follow the same framing; frame counts here are not multiples of 4 and hops are not
+    multiples of anything in particular, so the ragged last group and the unaligned loads are covered."""
+    from phasegen import ops
+    y = torch.from_numpy(np.stack([detgen.make_clip(n, seed=70 + i) for i in range(nsig)])).cuda()
+    try:
+        ops.set_stft_mode(1)
+        S1 = ops.stft(y, n_fft, hop)
+        lm = torch.log1p(torch.sqrt(S1[:, 0] ** 2 + S1[:, 1] ** 2)).contiguous()
+        ph = torch.atan2(S1[:, 1], S1[:, 0]).contiguous()
+        r1 = ops.istft(S1[:, 0].contiguous(), S1[:, 1].contiguous(), hop, mode=1, normalize=False)
+        e1 = ops.istft(lm, ph, hop, mode=0, normalize=True)
+        ops.set_stft_mode(0)
+        S0 = ops.stft(y, n_fft, hop)
+        r0 = ops.istft(S1[:, 0].contiguous(), S1[:, 1].contiguous(), hop, mode=1, normalize=False)
+        e0 = ops.istft(lm, ph, hop, mode=0, normalize=True)
+    finally:
+        ops.set_stft_mode(0)
+    want = np.stack([signal_ref.chunk_and_stft(y[i].cpu().numpy(), n_fft, hop) for i in range(nsig)])
+    assert relmax(S0, want) < 2e-5 and relmax(S1, want) < 2e-5
+    assert relmax(r0, r1.cpu().numpy()) < 2e-5 and relmax(e0, e1.cpu().numpy()) < 5e-5
+
+
 def test_generate_audio_and_fused_synthesis_vs_golden(golden_dir):
     from phasegen import audio
     g = np.load(os.path.join(golden_dir, "demo_g5.npz"))

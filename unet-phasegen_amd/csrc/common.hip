@@ -7,6 +7,17 @@
 
 static thread_local char g_err[256] = "";
 
+int pg_cu_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 int pg_fail(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s (code %d)", msg ? msg : "error", code);
     return code;

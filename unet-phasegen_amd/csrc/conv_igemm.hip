@@ -927,17 +927,7 @@ int g_force_mode = 0;   // work split: 0 automatic, 1 one tile per workgroup, 2 
 int g_force_raw = 0;    // 1 = never use the raw-window kernels (exercise the im2col kernels)
 int g_oversub = 4;      // stream-K grid = up to g_oversub x resident workgroup slots
 
-// Number of CUs of the current device (immutable per device; cached).
-int cu_count() {
-    static int cached[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-    if (!cached[dev]) {
-        int n = 0;
-        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return cached[dev];
-}
+int cu_count() { return pg_cu_count(); }
 
 // Grid policy.  Default: a persistent stream-K grid of up to g_oversub (4) x the resident workgroup slots, each
 // workgroup owning an equal contiguous range of the (tile, slab) space, plus the fixup launch.  Measured on MI355X

@@ -4,6 +4,8 @@
 
 // Records `msg` as the calling thread's last error and returns `code` (see pg_last_error_string()).
 int pg_fail(int code, const char* msg);
+// Number of CUs of the current device (immutable per device; cached).
+int pg_cu_count();
 
 // Wave(64)-level and block-level sum reductions (wavefront shuffles, then 4..16 partials through LDS).
 __device__ __forceinline__ float pg_wave_sum(float v) {

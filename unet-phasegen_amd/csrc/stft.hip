@@ -88,6 +88,325 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(const pg_stft_args a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched transforms: SF consecutive frames of one signal per group, real FFT through an (n_fft/2)-point complex
+// transform (even samples -> re, odd -> im, then the split X[k] = E[k] + w^k O[k]).  Workgroups are persistent (two
+// per CU) and walk the groups of their XCD, so the twiddle tables, window values and split factors are built once per
+// workgroup; inside a pass the index math and twiddles are shared by the SF frames.  Radix-4 Stockham passes give one
+// butterfly per thread per pass at n_fft = 2048.  LDS indices go through swz(), a GF(2)-linear swizzle under which
+// every read (32-lane groups, 64 banks) and write (16-lane groups, 32 banks) of every pass is conflict-free; twiddles
+// are stored per pass in butterfly order, so their reads are contiguous too.
+// The frame-minor output (bins, frames) is written SF frames (16 B) per row; consecutive groups -- the ones sharing
+// a 128 B line -- run on the same XCD, i.e. behind the same L2.
+constexpr int SF = 4;
+constexpr int MAX_HALF = 1024;                       // n_fft <= 2048
+constexpr int BT = 256;                              // threads per workgroup (512 measured slower: the store phase dominates)
+constexpr int M_ITERS = MAX_HALF / BT;               // points per thread and frame in the load / store phases
+constexpr int K_ITERS = (MAX_HALF / 2 + BT - 1) / BT; // bin pairs (k, M-k) per thread
+constexpr int FG = BT / 256, PF = SF / FG;           // passes: thread = (butterfly j, frame subset fg), PF frames each
+
+__device__ __forceinline__ int swz(int e) { return e ^ (((e >> 4) & 1) * 5) ^ (((e >> 5) & 1) * 10); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
+    return make_float2(__fmaf_rn(a.x, w.x, -(a.y * w.y)), __fmaf_rn(a.x, w.y, a.y * w.x));
+}
+
+// Twiddles of the radix-4 passes: the pass with sub-transform length Ns uses w^(r k), w = exp(-+ 2 pi i / (4 Ns)),
+// k < Ns, r = 1..3, stored at T_r[(Ns - 1) / 3 + k] with T_r = tw + (r - 1) * TL, TL = tw_len(M).
+__device__ __host__ __forceinline__ int tw_len(int M) { return M / 3 + 1; }
+__device__ void fill_tw4(float2* tw, int M, float sign) {
+    const int TL = tw_len(M);
+    for (int Ns = 1; Ns * 4 <= M; Ns <<= 2) {
+        const int off = (Ns - 1) / 3;
+        for (int k = threadIdx.x; k < Ns; k += blockDim.x) {
+            const float ang = sign * 2.0f * (float)k / (float)(4 * Ns);
+#pragma unroll
+            for (int r = 1; r <= 3; ++r) {
+                float sn, cs;
+                sincospif(ang * (float)r, &sn, &cs);
+                tw[(r - 1) * TL + off + k] = make_float2(cs, sn);
+            }
+        }
+    }
+}
+
+// M-point complex transforms of SF frames stored as x[f*M + swz(e)]; DIR = +1 forward, -1 inverse (unnormalised).
+// Returns the buffer holding the natural-order result.  Ends with a barrier.
+template <int DIR>
+__device__ float2* fft_frames(float2* x, float2* y, const float2* tw, int M) {
+    const int q = M >> 2, TL = tw_len(M);
+    const int jt = threadIdx.x & 255, f0 = (int)(threadIdx.x >> 8) * PF;
+    x += f0 * M; y += f0 * M;                      // this thread's frames (the swap below keeps the offset)
+    int Ns = 1;
+    for (; Ns * 4 <= M; Ns <<= 2) {
+        const int off = (Ns - 1) / 3;
+        for (int j = jt; j < q; j += 256) {
+            const int k = j & (Ns - 1);
+            const float2 w1 = tw[off + k], w2 = tw[TL + off + k], w3 = tw[2 * TL + off + k];
+            const int i0 = swz(j), i1 = swz(j + q), i2 = swz(j + 2 * q), i3 = swz(j + 3 * q);
+            const int j0 = ((j - k) << 2) + k;
+            const int o0 = swz(j0), o1 = swz(j0 + Ns), o2 = swz(j0 + 2 * Ns), o3 = swz(j0 + 3 * Ns);
+#pragma unroll
+            for (int f = 0; f < PF; ++f) {
+                const float2* xf = x + f * M;
+                float2* yf = y + f * M;
+                float2 a = xf[i0], b = xf[i1], c = xf[i2], d = xf[i3];
+                if (Ns > 1) { b = cmul(b, w1); c = cmul(c, w2); d = cmul(d, w3); }          // first pass: all twiddles are 1
+                const float2 s0 = make_float2(a.x + c.x, a.y + c.y), s1 = make_float2(a.x - c.x, a.y - c.y);
+                const float2 s2 = make_float2(b.x + d.x, b.y + d.y), s3 = make_float2(b.x - d.x, b.y - d.y);
+                const float2 r3 = DIR > 0 ? make_float2(s3.y, -s3.x) : make_float2(-s3.y, s3.x);   // -/+ i * s3
+                yf[o0] = make_float2(s0.x + s2.x, s0.y + s2.y);
+                yf[o1] = make_float2(s1.x + r3.x, s1.y + r3.y);
+                yf[o2] = make_float2(s0.x - s2.x, s0.y - s2.y);
+                yf[o3] = make_float2(s1.x - r3.x, s1.y - r3.y);
+            }
+        }
+        __syncthreads();
+        float2* t = x; x = y; y = t;
+    }
+    if (Ns < M) {                                  // log2 M odd: one closing radix-2 pass, twiddle computed in place
+        const int half = M >> 1;
+        for (int j = jt; j < half; j += 256) {
+            float sn, cs;
+            sincospif((DIR > 0 ? -1.0f : 1.0f) * (float)j / (float)half, &sn, &cs);       // k = j here: Ns == half
+            const float2 w = make_float2(cs, sn);
+            const int i0 = swz(j), i1 = swz(j + half), o0 = swz(j), o1 = swz(j + half);
+#pragma unroll
+            for (int f = 0; f < PF; ++f) {
+                const float2 a = x[f * M + i0], v = cmul(x[f * M + i1], w);
+                y[f * M + o0] = make_float2(a.x + v.x, a.y + v.y);
+                y[f * M + o1] = make_float2(a.x - v.x, a.y - v.y);
+            }
+        }
+        __syncthreads();
+        float2* t = x; x = y; y = t;
+    }
+    return x - f0 * M;
+}
+
+// one output row, SF consecutive frames: a 16 B store when the row segment is aligned, scalar stores otherwise
+__device__ __forceinline__ void stft_store_row(const pg_stft_args& a, float* o_re, float* o_im, long row, int nfr, bool vec,
+                                               float (&re)[SF], float (&im)[SF]) {
+    if (a.polar) {
+#pragma unroll
+        for (int f = 0; f < SF; ++f) {
+            float r = re[f], i = im[f];
+            pg_complex_from_parts(r, i);
+            re[f] = log1pf(hypotf(r, i));
+            im[f] = atan2f(i, r);
+        }
+    }
+    float* pr = o_re + row * a.n_frames;
+    float* pi = o_im + row * a.n_frames;
+    if (vec) {
+        *(float4*)pr = make_float4(re[0], re[1], re[2], re[3]);
+        *(float4*)pi = make_float4(im[0], im[1], im[2], im[3]);
+    } else {
+#pragma unroll
+        for (int f = 0; f < SF; ++f)
+            if (f < nfr) { pr[f] = re[f]; pi[f] = im[f]; }
+    }
+}
+
+// The groups of this workgroup: XCD x (workgroups are dealt round-robin over the 8 XCDs) owns the contiguous range
+// [x * chunk, (x + 1) * chunk), walked by its gridDim.x / 8 workgroups with that stride.
+struct GroupWalk { int g, end, step; };
+__device__ __forceinline__ GroupWalk group_walk(int total) {
+    const int chunk = (total + 7) >> 3, xcd = blockIdx.x & 7;
+    GroupWalk w;
+    w.g = xcd * chunk + (int)(blockIdx.x >> 3);
+    w.end = min(total, (xcd + 1) * chunk);
+    w.step = (int)(gridDim.x >> 3);
+    return w;
+}
+
+__global__ __launch_bounds__(BT) void stft_frames_kernel(const pg_stft_args a) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int N = a.n_fft, M = N >> 1;
+    float2* x = smem; float2* y = smem + SF * M; float2* tw = smem + 2 * SF * M;
+    const int groups = (a.n_frames + SF - 1) / SF, total = a.n_signals * groups;
+    fill_tw4(tw, M, -1.f);
+    // per-thread constants: window values of its sample pairs, split factors w^k of its bin pairs
+    float w0[M_ITERS], w1[M_ITERS], sc[K_ITERS], ss[K_ITERS];
+#pragma unroll
+    for (int i = 0; i < M_ITERS; ++i) {
+        const int m = threadIdx.x + i * BT;
+        w0[i] = hann(2 * m, N); w1[i] = hann(2 * m + 1, N);
+    }
+#pragma unroll
+    for (int i = 0; i < K_ITERS; ++i)
+        sincospif(-(float)(1 + threadIdx.x + i * BT) / (float)M, &ss[i], &sc[i]);   // w = exp(-2 pi i / n_fft)
+    const bool vec2 = ((a.hop | a.n_samples) & 1) == 0 && (((uintptr_t)a.y) & 7) == 0;       // sample pairs are 8 B aligned
+    const bool vec4 = (a.n_frames & 3) == 0 && (((uintptr_t)a.out) & 15) == 0;               // row segments are 16 B aligned
+    __syncthreads();
+    // sample pairs of one group -> registers (windowing and the LDS write happen one iteration later, so the loads of
+    // group i+1 are in flight during the passes of group i)
+    float2 pre[M_ITERS][SF];
+    auto load_group = [&](int g) {
+        const int sig = g / groups, t0 = (g - sig * groups) * SF;
+        const int nfr = min(SF, a.n_frames - t0);
+        const float* sgn = a.y + (long)sig * a.n_samples;
+#pragma unroll
+        for (int i = 0; i < M_ITERS; ++i) {
+            const int m = threadIdx.x + i * BT;
+#pragma unroll
+            for (int f = 0; f < SF; ++f) {
+                float v0 = 0.f, v1 = 0.f;
+                if (m < M && f < nfr) {
+                    const int start = (t0 + f) * a.hop - M, p = start + 2 * m;              // frame tap k sits at start + k
+                    if (start >= 0 && start + N <= a.n_samples) {
+                        if (vec2) { const float2 v = *(const float2*)(sgn + p); v0 = v.x; v1 = v.y; }
+                        else { v0 = sgn[p]; v1 = sgn[p + 1]; }
+                    } else { v0 = sgn[reflect_index(p, a.n_samples)]; v1 = sgn[reflect_index(p + 1, a.n_samples)]; }
+                }
+                pre[i][f] = make_float2(v0, v1);
+            }
+        }
+    };
+    GroupWalk gw = group_walk(total);
+    if (gw.g < gw.end) load_group(gw.g);
+    for (; gw.g < gw.end; gw.g += gw.step) {
+        const int sig = gw.g / groups, t0 = (gw.g - sig * groups) * SF;
+        const int nfr = min(SF, a.n_frames - t0);
+#pragma unroll
+        for (int i = 0; i < M_ITERS; ++i) {
+            const int m = threadIdx.x + i * BT;
+            if (m < M) {
+                const int e = swz(m);
+#pragma unroll
+                for (int f = 0; f < SF; ++f) x[f * M + e] = make_float2(pre[i][f].x * w0[i], pre[i][f].y * w1[i]);
+            }
+        }
+        __syncthreads();
+        if (gw.g + gw.step < gw.end) load_group(gw.g + gw.step);
+        const float2* Z = fft_frames<1>(x, y, tw, M);
+        float* o_re = a.out + ((long)sig * 2 * M) * a.n_frames + t0;
+        float* o_im = o_re + (long)M * a.n_frames;
+        const bool vec = vec4 && nfr == SF;
+#pragma unroll
+        for (int i = 0; i < K_ITERS; ++i) {                               // bins k and M-k from Z[k], Z[M-k]; DC dropped
+            const int k = 1 + threadIdx.x + i * BT;
+            if (k <= (M >> 1)) {
+                const int ea = swz(k), eb = swz(M - k);
+                float rk[SF], ik[SF], rm[SF], im[SF];
+#pragma unroll
+                for (int f = 0; f < SF; ++f) {                                // frames past the end were loaded as zeros
+                    const float2 A = Z[f * M + ea], B = Z[f * M + eb];
+                    const float2 E = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
+                    const float2 O = make_float2(0.5f * (A.y + B.y), -0.5f * (A.x - B.x));
+                    const float2 T = cmul(O, make_float2(sc[i], ss[i]));
+                    rk[f] = E.x + T.x; ik[f] = E.y + T.y;
+                    rm[f] = E.x - T.x; im[f] = T.y - E.y;
+                }
+                stft_store_row(a, o_re, o_im, k - 1, nfr, vec, rk, ik);
+                if (k != M - k) stft_store_row(a, o_re, o_im, M - k - 1, nfr, vec, rm, im);
+            }
+        }
+        if (threadIdx.x == 0) {                                               // Nyquist bin: X[M] = Re Z0 - Im Z0
+            float rn[SF], in[SF];
+#pragma unroll
+            for (int f = 0; f < SF; ++f) { const float2 Z0 = Z[f * M]; rn[f] = Z0.x - Z0.y; in[f] = 0.f; }
+            stft_store_row(a, o_re, o_im, M - 1, nfr, vec, rn, in);
+        }
+        __syncthreads();                                                      // Z may live in the buffer the next group loads into
+    }
+}
+
+// SF consecutive frames of spectrum row `bin` (1-based FFT bin) as complex values; frames past the end read as zero
+__device__ __forceinline__ void istft_row(const pg_istft_args& a, const float* pa, const float* pb, int bin, int nfr, bool vec,
+                                          float2 (&X)[SF]) {
+    float va[SF], vb[SF];
+    const float* ra = pa + (long)(bin - 1) * a.n_frames;
+    const float* rb = pb + (long)(bin - 1) * a.n_frames;
+    if (vec) {
+        const float4 qa = *(const float4*)ra, qb = *(const float4*)rb;
+        va[0] = qa.x; va[1] = qa.y; va[2] = qa.z; va[3] = qa.w;
+        vb[0] = qb.x; vb[1] = qb.y; vb[2] = qb.z; vb[3] = qb.w;
+    } else {
+#pragma unroll
+        for (int f = 0; f < SF; ++f) { va[f] = f < nfr ? ra[f] : 0.f; vb[f] = f < nfr ? rb[f] : 0.f; }
+    }
+#pragma unroll
+    for (int f = 0; f < SF; ++f) {
+        if (a.mode == 0) {                                                // demo.py:39: (exp(m) - 1) e^{j phi}
+            const float mag = expf(va[f]) - 1.0f;
+            float s, c;
+            sincosf(vb[f], &s, &c);
+            X[f] = make_float2(mag * c, mag * s);
+        } else X[f] = make_float2(va[f], vb[f]);
+    }
+}
+
+__global__ __launch_bounds__(BT) void istft_frames4_kernel(const pg_istft_args a, float* frames) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int M = a.bins, N = 2 * M;
+    float2* x = smem; float2* y = smem + SF * M; float2* tw = smem + 2 * SF * M;
+    const int groups = (a.n_frames + SF - 1) / SF, total = a.n_signals * groups;
+    fill_tw4(tw, M, 1.f);
+    float w0[M_ITERS], w1[M_ITERS], sc[K_ITERS], ss[K_ITERS];
+    const float inv = 1.0f / (float)M;
+#pragma unroll
+    for (int i = 0; i < M_ITERS; ++i) {
+        const int m = threadIdx.x + i * BT;
+        w0[i] = inv * hann(2 * m, N); w1[i] = inv * hann(2 * m + 1, N);
+    }
+#pragma unroll
+    for (int i = 0; i < K_ITERS; ++i)
+        sincospif((float)(1 + threadIdx.x + i * BT) / (float)M, &ss[i], &sc[i]);    // exp(+2 pi i k / n_fft)
+    const bool vec4 = (a.n_frames & 3) == 0 && ((a.a_bs | a.b_bs) & 3) == 0 && ((((uintptr_t)a.a) | ((uintptr_t)a.b)) & 15) == 0;
+    __syncthreads();
+    for (GroupWalk gw = group_walk(total); gw.g < gw.end; gw.g += gw.step) {
+        const int sig = gw.g / groups, t0 = (gw.g - sig * groups) * SF;
+        const int nfr = min(SF, a.n_frames - t0);
+        const float* pa = a.a + (long)sig * a.a_bs + t0;
+        const float* pb = a.b + (long)sig * a.b_bs + t0;
+        const bool vec = vec4 && nfr == SF;
+        // Z[k] = E[k] + i O[k] with E = (X[k] + conj X[M-k]) / 2, O = (X[k] - conj X[M-k]) / 2 * exp(+2 pi i k / n_fft);
+        // X[0] = 0 (the zero DC row of utils.py:38-39), X[M] real (irfft ignores the Nyquist imaginary part)
+#pragma unroll
+        for (int i = 0; i < K_ITERS; ++i) {
+            const int k = 1 + threadIdx.x + i * BT;
+            if (k <= (M >> 1)) {
+                const int ea = swz(k), eb = swz(M - k);
+                float2 Xk[SF], Xm[SF];
+                istft_row(a, pa, pb, k, nfr, vec, Xk);
+                istft_row(a, pa, pb, M - k, nfr, vec, Xm);
+#pragma unroll
+                for (int f = 0; f < SF; ++f) {
+                    const float2 E = make_float2(0.5f * (Xk[f].x + Xm[f].x), 0.5f * (Xk[f].y - Xm[f].y));
+                    const float2 D = make_float2(0.5f * (Xk[f].x - Xm[f].x), 0.5f * (Xk[f].y + Xm[f].y));
+                    const float2 O = cmul(D, make_float2(sc[i], ss[i]));
+                    x[f * M + ea] = make_float2(E.x - O.y, E.y + O.x);
+                    if (k != M - k) x[f * M + eb] = make_float2(E.x + O.y, O.x - E.y);
+                }
+            }
+        }
+        if (threadIdx.x == 0) {
+            float2 Xn[SF];
+            istft_row(a, pa, pb, M, nfr, vec, Xn);
+#pragma unroll
+            for (int f = 0; f < SF; ++f) x[f * M] = make_float2(0.5f * Xn[f].x, -0.5f * Xn[f].x);
+        }
+        __syncthreads();
+        const float2* z = fft_frames<-1>(x, y, tw, M);
+#pragma unroll
+        for (int i = 0; i < M_ITERS; ++i) {
+            const int m = threadIdx.x + i * BT;
+            if (m < M) {
+                const int e = swz(m);
+#pragma unroll
+                for (int f = 0; f < SF; ++f) {
+                    if (f >= nfr) break;
+                    const float2 v = z[f * M + e];
+                    float2* dst = (float2*)(frames + ((long)sig * a.n_frames + t0 + f) * N) + m;
+                    *dst = make_float2(v.x * w0[i], v.y * w1[i]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void frame_index_kernel(int n_samples, int n_fft, int hop, int n_frames, int* idx) {
     const long total = (long)n_frames * n_fft;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -126,36 +445,87 @@ __global__ __launch_bounds__(FFT_THREADS) void istft_frames_kernel(const pg_istf
     for (int n = threadIdx.x; n < N; n += blockDim.x) f[n] = x[n].x * inv * hann(n, N);
 }
 
-// overlap-add as a gather + / window-sum-square + trim + peak |y|
-__global__ __launch_bounds__(256) void istft_ola_kernel(const pg_istft_args a, const float* frames, unsigned* peak) {
-    __shared__ float scratch[16];
+// Overlap-add, 4 consecutive samples per thread: the <= n_fft/hop frames covering them are read as 16 B pieces, the
+// squared-window sum follows the frames by rotating (cos, sin) instead of re-evaluating the window, and each workgroup
+// leaves its peak in partial[] (no atomics: thousands of same-line device-scope atomics were most of the old kernel's time).
+constexpr int OLA_SPT = 4;
+
+__global__ __launch_bounds__(256) void istft_ola4_kernel(const pg_istft_args a, const float* frames, float* partial) {
+    __shared__ float scratch[4];
     const int N = 2 * a.bins, len = a.hop * (a.n_frames - 1);
     const int sig = blockIdx.y;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * OLA_SPT;
+    const float* fs = frames + (long)sig * a.n_frames * N;
     float mx = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
-        const int ip = i + (N >> 1);
-        int t_hi = ip / a.hop; if (t_hi > a.n_frames - 1) t_hi = a.n_frames - 1;
-        int t_lo = (ip - N + a.hop) / a.hop; if (ip - N + 1 <= 0) t_lo = 0;          // ceil((ip-N+1)/hop), clamped
-        float s = 0.f, wss = 0.f;
-        for (int t = t_lo; t <= t_hi; ++t) {
-            const int n = ip - t * a.hop;
-            const float w = hann(n, N);
-            s += frames[((long)sig * a.n_frames + t) * N + n];
-            wss += w * w;
+    if (i0 < len) {
+        float* out = a.audio + (long)sig * len + i0;
+        const bool vec = (a.hop & 3) == 0 && N <= 16 * a.hop && i0 + OLA_SPT <= len && (((uintptr_t)a.audio) & 15) == 0;
+        if (vec) {                                   // ip, hop, N/2 are multiples of 4: the 4 samples share their frame range
+            const int ip = i0 + (N >> 1);
+            int t_hi = ip / a.hop; if (t_hi > a.n_frames - 1) t_hi = a.n_frames - 1;
+            int t_lo = (ip - N + a.hop) / a.hop; if (ip - N + 1 <= 0) t_lo = 0;
+            float sd, cd, sh, ch, c[OLA_SPT], sn[OLA_SPT];
+            sincospif(2.0f / (float)N, &sd, &cd);
+            sincospif(2.0f * (float)a.hop / (float)N, &sh, &ch);
+            sincospif(2.0f * (float)(ip - t_lo * a.hop) / (float)N, &sn[0], &c[0]);
+#pragma unroll
+            for (int j = 1; j < OLA_SPT; ++j) { c[j] = c[j - 1] * cd - sn[j - 1] * sd; sn[j] = sn[j - 1] * cd + c[j - 1] * sd; }
+            float acc[OLA_SPT] = {0.f, 0.f, 0.f, 0.f}, wss[OLA_SPT] = {0.f, 0.f, 0.f, 0.f};
+            for (int t = t_lo; t <= t_hi; ++t) {
+                const float4 v = *(const float4*)(fs + (long)t * N + (ip - t * a.hop));
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+#pragma unroll
+                for (int j = 0; j < OLA_SPT; ++j) {
+                    const float w = 0.5f - 0.5f * c[j];
+                    wss[j] += w * w;
+                    const float cn = c[j] * ch + sn[j] * sh;             // the next frame sees this sample hop taps earlier
+                    sn[j] = sn[j] * ch - c[j] * sh;
+                    c[j] = cn;
+                }
+            }
+            float y[OLA_SPT];
+#pragma unroll
+            for (int j = 0; j < OLA_SPT; ++j) {
+                y[j] = wss[j] > 1.17549435e-38f ? acc[j] / wss[j] : acc[j];
+                mx = fmaxf(mx, fabsf(y[j]));
+            }
+            *(float4*)out = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+            for (int j = 0; j < OLA_SPT && i0 + j < len; ++j) {
+                const int ip = i0 + j + (N >> 1);
+                int t_hi = ip / a.hop; if (t_hi > a.n_frames - 1) t_hi = a.n_frames - 1;
+                int t_lo = (ip - N + a.hop) / a.hop; if (ip - N + 1 <= 0) t_lo = 0;          // ceil((ip-N+1)/hop), clamped
+                float sum = 0.f, wss = 0.f;
+                for (int t = t_lo; t <= t_hi; ++t) {
+                    const int n = ip - t * a.hop;
+                    const float w = hann(n, N);
+                    sum += fs[(long)t * N + n];
+                    wss += w * w;
+                }
+                const float yv = wss > 1.17549435e-38f ? sum / wss : sum;
+                out[j] = yv;
+                mx = fmaxf(mx, fabsf(yv));
+            }
         }
-        const float yv = wss > 1.17549435e-38f ? s / wss : s;
-        a.audio[(long)sig * len + i] = yv;
-        mx = fmaxf(mx, fabsf(yv));
     }
-    // block max, then one atomicMax on the float bits (non-negative floats order like unsigned ints)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) mx = fmaxf(mx, scratch[i]);
-        atomicMax(peak + sig, __float_as_uint(mx));
-    }
+    if (threadIdx.x == 0) partial[(long)sig * gridDim.x + blockIdx.x] = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+}
+
+// per-signal peak = max over the workgroup partials (fixed order; max is exact in any order anyway)
+__global__ __launch_bounds__(256) void istft_peak_kernel(const float* partial, int nblk, unsigned* peak) {
+    __shared__ float scratch[4];
+    const int sig = blockIdx.x;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) mx = fmaxf(mx, partial[(long)sig * nblk + i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) peak[sig] = __float_as_uint(fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3])));
 }
 
 __global__ __launch_bounds__(256) void istft_normalize_kernel(float* audio, int len, const unsigned* peak) {
@@ -214,6 +584,20 @@ __global__ __launch_bounds__(256) void ola_nt_kernel(const pg_ola_args a, unsign
 
 bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+// the batched kernels hold 2 x SF frames of n_fft/2 complex points plus the twiddle table: 72 KB at n_fft = 2048
+constexpr int BATCHED_MAX_NFFT = 2048;
+int g_stft_single = 0;                     // pg_stft_set_mode(1): one frame per workgroup, full-length radix-2 transform
+size_t batched_lds(int n_fft) { return (size_t)(2 * SF * (n_fft / 2) + 3 * tw_len(n_fft / 2)) * sizeof(float2); }
+int batched_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (2 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }
+hipError_t batched_lds_ready() {
+    static hipError_t st = [] {
+        hipError_t e = hipFuncSetAttribute((const void*)stft_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)batched_lds(BATCHED_MAX_NFFT));
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute((const void*)istft_frames4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)batched_lds(BATCHED_MAX_NFFT));
+    }();
+    return st;
+}
+
 }  // namespace
 
 extern "C" int pg_stft(const pg_stft_args* a, void* stream) {
@@ -221,11 +605,20 @@ extern "C" int pg_stft(const pg_stft_args* a, void* stream) {
     if (!pow2(a->n_fft) || a->n_fft < 32 || a->n_fft > 4096) return pg_fail(PG_ERR_UNSUPPORTED, "stft: n_fft must be a power of two in [32, 4096]");
     if (a->n_signals <= 0 || a->hop <= 0 || a->n_samples <= a->n_fft / 2) return pg_fail(PG_ERR_SHAPE, "stft: bad sizes (reflect padding needs n_samples > n_fft/2)");
     if (a->n_frames != 1 + a->n_samples / a->hop) return pg_fail(PG_ERR_SHAPE, "stft: n_frames must equal 1 + n_samples / hop");
-    const size_t lds = (size_t)(2 * a->n_fft + a->n_fft / 2) * sizeof(float2);
-    hipLaunchKernelGGL(stft_kernel, dim3((unsigned)(a->n_signals * a->n_frames)), dim3(FFT_THREADS), lds, (hipStream_t)stream, *a);
-    hipError_t e = hipGetLastError();
+    hipError_t e = batched_lds_ready();
+    if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
+    if (a->n_fft <= BATCHED_MAX_NFFT && !g_stft_single) {
+        const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
+        hipLaunchKernelGGL(stft_frames_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
+    } else {
+        const size_t lds = (size_t)(2 * a->n_fft + a->n_fft / 2) * sizeof(float2);
+        hipLaunchKernelGGL(stft_kernel, dim3((unsigned)(a->n_signals * a->n_frames)), dim3(FFT_THREADS), lds, (hipStream_t)stream, *a);
+    }
+    e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
 }
+
+extern "C" int pg_stft_set_mode(int32_t single_frame) { g_stft_single = single_frame ? 1 : 0; return PG_OK; }
 
 extern "C" int pg_stft_frame_index(int32_t n_samples, int32_t n_fft, int32_t hop, int32_t n_frames, int32_t* idx, void* stream) {
     if (!idx) return pg_fail(PG_ERR_NULL, "stft_frame_index: idx required");
@@ -236,10 +629,16 @@ extern "C" int pg_stft_frame_index(int32_t n_samples, int32_t n_fft, int32_t hop
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
 }
 
+static int ola_blocks(const pg_istft_args* a) { return (a->hop * (a->n_frames - 1) + 256 * OLA_SPT - 1) / (256 * OLA_SPT); }
+static int64_t ola_partial_bytes(const pg_istft_args* a) {
+    const int64_t b = (int64_t)a->n_signals * ola_blocks(a) * (int64_t)sizeof(float);
+    return (b + 255) / 256 * 256;
+}
+
 extern "C" int64_t pg_workspace_bytes_istft(const pg_istft_args* a) {
     if (!a) return 0;
-    // [peak words, padded to 256 B][frames]
-    return 256 + (int64_t)a->n_signals * a->n_frames * 2 * a->bins * (int64_t)sizeof(float);
+    // [peak words, 256 B][per-workgroup peaks of the overlap-add, padded to 256 B][frames]
+    return 256 + ola_partial_bytes(a) + (int64_t)a->n_signals * a->n_frames * 2 * a->bins * (int64_t)sizeof(float);
 }
 
 extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
@@ -250,14 +649,22 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
     if (a->workspace_bytes < pg_workspace_bytes_istft(a)) return pg_fail(PG_ERR_WORKSPACE, "istft: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     unsigned* peak = (unsigned*)a->workspace;
-    float* frames = (float*)((char*)a->workspace + 256);
-    hipError_t e = hipMemsetAsync(peak, 0, 256, st);
-    if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
-    const size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
-    hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)(a->n_signals * a->n_frames)), dim3(FFT_THREADS), lds, st, *a, frames);
+    float* partial = (float*)((char*)a->workspace + 256);
+    float* frames = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));
+    hipError_t e;
+    if ((e = batched_lds_ready()) != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
+    if (N <= BATCHED_MAX_NFFT && !g_stft_single) {
+        const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
+        hipLaunchKernelGGL(istft_frames4_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(N), st, *a, frames);
+    } else {
+        const size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
+        hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)(a->n_signals * a->n_frames)), dim3(FFT_THREADS), lds, st, *a, frames);
+    }
     const int len = a->hop * (a->n_frames - 1);
+    const int nblk = ola_blocks(a);
+    hipLaunchKernelGGL(istft_ola4_kernel, dim3(nblk, a->n_signals), dim3(256), 0, st, *a, (const float*)frames, partial);
     int bx = (len + 255) / 256; if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(istft_ola_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, *a, (const float*)frames, peak);
+    if (a->normalize) hipLaunchKernelGGL(istft_peak_kernel, dim3(a->n_signals), dim3(256), 0, st, (const float*)partial, nblk, peak);
     if (a->normalize) hipLaunchKernelGGL(istft_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const unsigned*)peak);
     e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));

@@ -97,6 +97,7 @@ SYMBOLS = {
     "pg_loss_fwd_bwd": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "pg_adam_step": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
     "pg_stft": (C.c_int, [C.POINTER(StftArgs), C.c_void_p]),
+    "pg_stft_set_mode": (C.c_int, [C.c_int32]),
     "pg_stft_frame_index": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pg_polar": (C.c_int, [C.POINTER(PolarArgs), C.c_void_p]),
     "pg_workspace_bytes_istft": (C.c_int64, [C.POINTER(IstftArgs)]),

@@ -100,6 +100,11 @@ def set_conv_oversubscribe(factor):
     _lib.check(_lib.load().pg_conv_set_oversubscribe(factor), "conv_set_oversubscribe")
 
 
+def set_stft_mode(single_frame):
+    """0: 4 frames per workgroup through the half-length radix-4 real FFT (default); 1: one frame per workgroup, radix-2."""
+    _lib.check(_lib.load().pg_stft_set_mode(int(bool(single_frame))), "stft_set_mode")
+
+
 def _conv_args(transposed, B, Cin, Cout, Lin, k, s, p, device=None):
     a = _lib.ConvArgs()
     a.B, a.Cin, a.Cout, a.Lin, a.k, a.stride, a.pad = B, Cin, Cout, Lin, k, s, p
