@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 DOMINANT_KERNEL = "conv_raw_kernel<32, 2, true>"   # the symbol rocprofv3 reports for the U0 forward launch
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 16 x the fp32 rate (v_mfma_f32_32x32x16_bf16: 32 cycles for 32 768 FLOP)
 
 
 def conv_flops(C, L, B):
@@ -107,6 +108,9 @@ def main():
     ap.add_argument("--channels", type=int, default=1024, help="C (bins); 1024 = the reference's hard-coded model")
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="MFMA operand precision: fp32 = the parity path and the headline; bf16 = BASELINE configs[4]'s arithmetic "
+                         "(bf16 operands, fp32 accumulate, fp32 tensors and master weights) -- reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None)
     a = ap.parse_args()
@@ -133,6 +137,8 @@ def main():
     from phasegen.trainer import Trainer
 
     C, L, B = a.channels, a.frames, a.batch
+    ops.set_conv_precision(a.precision)
+    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     torch.manual_seed(0)
     model = UNetModel(C, 2 * C, gpu_ids=[local])
     trainer = Trainer(model, lr=1e-3)
@@ -175,21 +181,22 @@ def main():
         out = {
             "metric": "spectrogram-frames/sec (train fwd+bwd)", "value": frames / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.precision == "fp32" else "bf16 operands / f32 accumulate", "data": "synthetic",
             "config": {"workload": f"train.py full step (fwd + cos/sin/mag loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}), "
                                    f"UNetModel({C}, {2 * C}), per-GPU batch {B} x {C} bins x {L} frames (BASELINE configs[2]{'/[3]' if world > 1 else ''})",
                        "global_batch": world * B, "frames": L, "channels": C, "parallelism": f"dp{world}",
                        "final_loss": loss_val},
             "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (U0 forward, ConvTranspose1d 4096->2048 k32 s2)",
-                         "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": pmc_traffic(DOMINANT_KERNEL) if (C, L, B) == (1024, 256, 64) else None,
+                         "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": dom["tflops"] / peak,
+                         "traffic": pmc_traffic(DOMINANT_KERNEL) if (C, L, B, a.precision) == (1024, 256, 64, "fp32") else None,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                          "flops_per_launch": fl["U0"], "ms_per_launch": dom["ms"],
                          "step_tflops": round((3 * sum(fl.values()) - fl["D0"]) / (dt / a.steps) / 1e12, 2)},
             "kernels": ks,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.precision == "fp32":
             del trainer, model, batch
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(C, L, a.cpu_threads)

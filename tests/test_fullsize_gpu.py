@@ -31,18 +31,36 @@ def schedule(request):
 
 @pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
 def test_conv_layer_at_full_size(layer, schedule):
+    check_layer(layer, bf16=False)
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_conv_layer_at_full_size_bf16_operands(layer):
+    """The same checks with pg_conv_set_precision(1).  x, w and dy are made bf16-representable, so the operand rounding
+    only acts on LeakyReLU outputs (0.2 x is not representable) and the host recomputation -- on the rounded activated
+    operand -- is exact for the raw-window kernels and for the fp32 fallback passes alike."""
+    from phasegen import ops
+    ops.set_conv_precision("bf16")
+    try:
+        check_layer(layer, bf16=True)
+    finally:
+        ops.set_conv_precision("fp32")
+
+
+def check_layer(layer, bf16):
     from phasegen import ops
     name, tr, Cin, Cout, k, s, p, Lin, act = layer
     Lout = ops.convt_out_len(Lin, k, s, p) if tr else ops.conv_out_len(Lin, k, s, p)
     g = torch.Generator(device="cuda").manual_seed(sum(map(ord, name)))
-    x = torch.randn(B, Cin, Lin, device="cuda", generator=g)
-    w = torch.randn((Cin, Cout, k) if tr else (Cout, Cin, k), device="cuda", generator=g) * 0.02
-    dy = torch.randn(B, Cout, Lout, device="cuda", generator=g)
+    rb = (lambda t: t.to(torch.bfloat16).float()) if bf16 else (lambda t: t)
+    x = rb(torch.randn(B, Cin, Lin, device="cuda", generator=g))
+    w = rb(torch.randn((Cin, Cout, k) if tr else (Cout, Cin, k), device="cuda", generator=g) * 0.02)
+    dy = rb(torch.randn(B, Cout, Lout, device="cuda", generator=g))
     y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
     ops.conv_fwd(x, w, y, s, p, x_act=act, transposed=tr)
     ops.conv_dgrad(dy, w, dx, s, p, transposed=tr)
     ops.conv_wgrad(x, dy, dw, s, p, x_act=act, transposed=tr)
-    xa = torch.nn.functional.leaky_relu(x, 0.2) if act == 1 else (torch.relu(x) if act == 2 else x)
+    xa = rb(torch.nn.functional.leaky_relu(x, 0.2) if act == 1 else (torch.relu(x) if act == 2 else x))
     # --- adjoint identities (float64 reductions of the device tensors)
     d1 = float((y.double() * dy.double()).sum())
     d2 = float((xa.double() * dx.double()).sum())
@@ -135,3 +153,33 @@ def test_full_size_step_is_reproducible_and_schedule_independent():
         den = float(results[0][1].double().norm())
         assert num < 2e-2 * den, (num, den)
     assert torch.isfinite(results[0][0]).all() and 0.5 < float(results[0][0][0]) < 10
+
+
+def test_full_size_step_bf16_operands_tracks_fp32():
+    """Config 5's arithmetic (bf16 MFMA operands, fp32 accumulate, fp32 master weights) on the full-size step: losses
+    within 1 % of the fp32 step; gradient within 25 % of its norm (measured 11 %: at this random initialisation the gradient is
+    so sensitive to ReLU-mask flips that re-ordering the fp32 sums alone moves it by 0.4 %, see the test above, and operand
+    rounding is a 2^-9 perturbation per product).  Not the 1e-4 parity path; every layer taken alone is exact to 1e-4
+    against the rounded-operand recomputation (test_conv_layer_at_full_size_bf16_operands)."""
+    from phasegen import ops
+    from phasegen.model import UNetModel
+    from phasegen.trainer import Trainer
+    g = torch.Generator(device="cuda").manual_seed(3)
+    batch = torch.stack([torch.rand(16, C, L, device="cuda", generator=g) * 3,
+                         (torch.rand(16, C, L, device="cuda", generator=g) * 2 - 1) * torch.pi], dim=1).contiguous()
+    res = []
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(11)
+        m = UNetModel(C, 2 * C)
+        tr = Trainer(m)
+        ops.set_conv_precision(prec)
+        try:
+            losses = tr.step(batch).clone()
+        finally:
+            ops.set_conv_precision("fp32")
+        res.append((losses, m.engine.arena.grad.clone()))
+        del tr, m
+        torch.cuda.empty_cache()
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-2), (res[0][0], res[1][0])
+    num = float((res[0][1].double() - res[1][1].double()).norm()), float(res[0][1].double().norm())
+    assert num[0] < 0.25 * num[1], num

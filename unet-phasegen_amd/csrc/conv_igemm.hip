@@ -538,7 +538,31 @@ __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, con
     }
 }
 
+// bf16 operand mode (pg_conv_set_precision(1)): the same fragments -- lane (row, h) already holds k = 8h .. 8h+7 of the
+// slab, which is exactly the operand layout of v_mfma_f32_32x32x16_bf16 -- are rounded to bf16 (RNE, v_cvt_pk_bf16_f32)
+// after the activation and one MFMA replaces eight; accumulation stays fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 to_bf16x8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    bf16x8 r;
+    r[0] = (__bf16)v0; r[1] = (__bf16)v1; r[2] = (__bf16)v2; r[3] = (__bf16)v3;
+    r[4] = (__bf16)v4; r[5] = (__bf16)v5; r[6] = (__bf16)v6; r[7] = (__bf16)v7;
+    return r;
+}
+__device__ __forceinline__ void mfma_bf16_2x4(const f32x4 (&a)[2][2], const float (&b)[4][8], AccR& acc) {
+    bf16x8 A[2], B[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) A[i] = to_bf16x8(a[i][0][0], a[i][0][1], a[i][0][2], a[i][0][3], a[i][1][0], a[i][1][1], a[i][1][2], a[i][1][3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) B[j] = to_bf16x8(b[j][0], b[j][1], b[j][2], b[j][3], b[j][4], b[j][5], b[j][6], b[j][7]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc.c[i][j], 0, 0, 0);
+}
+
+template <bool BF>
 __device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
+    if (BF) { mfma_bf16_2x4(f.a, f.b, acc); return; }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
@@ -548,17 +572,17 @@ __device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
                 acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk >> 2][kk & 3], f.b[j][kk], acc.c[i][j], 0, 0, 0);
 }
 
-template <int TJ, bool DESC, int RS>
+template <int TJ, bool DESC, int RS, bool BF>
 __device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
                                              const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
     RawFrags f;
     raw_load_frags<TJ, DESC, RS>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
-    raw_mfma(f, acc);
+    raw_mfma<BF>(f, acc);
 }
 
 // TKIND false: F (conv fwd / convT dgrad, taps ascend with stride s between columns)
 // TKIND true : T (convT fwd / conv dgrad in gather form, unit column stride, taps descend)
-template <int KW, int S, bool TKIND>
+template <int KW, int S, bool TKIND, bool BF>
 __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
     constexpr int TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ;
@@ -688,9 +712,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             for (int hf = 0; hf < SPB; ++hf) RAW_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, (sl + SPB + hf) * BK)
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(1)
-            mma_slab_raw<TJ, TKIND, RS>(lds + cur * SSTG, lds + cur * SSTG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
+            mma_slab_raw<TJ, TKIND, RS, BF>(lds + cur * SSTG, lds + cur * SSTG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
             if (SPB == 2 && sl + 1 < se)
-                mma_slab_raw<TJ, TKIND, RS>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
+                mma_slab_raw<TJ, TKIND, RS, BF>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + RTILE_A, lane, wm, bbase, slopeA, slopeB, acc);
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(2)
             __syncthreads();
@@ -725,7 +749,7 @@ template <int KW, int S> struct GRaw {
     static_assert(WL <= WLP, "window does not fit its slot");
 };
 
-template <int KW, int S>
+template <int KW, int S, bool BF>
 __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) {
     using C = GRaw<KW, S>;
     __shared__ __attribute__((aligned(16))) float lds[2 * C::STG];
@@ -851,13 +875,16 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
 #pragma unroll
                         for (int i = 0; i < 8; ++i) b[jb][i] = act_apply(b[jb][i], slopeB);
                 }
+                if (BF) mfma_bf16_2x4(a, b, acc);
+                else {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
+                    for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk], acc.c[i][j], 0, 0, 0);
+                            for (int j = 0; j < 4; ++j)
+                                acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk], acc.c[i][j], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             kc_cur = kc_next;
@@ -926,6 +953,7 @@ constexpr long WS_PER_WG = 2L * ACC_REGS * NT * 4;   // two partial tiles of 256
 int g_force_mode = 0;   // work split: 0 automatic, 1 one tile per workgroup, 2 force stream-K
 int g_force_raw = 0;    // 1 = never use the raw-window kernels (exercise the im2col kernels)
 int g_oversub = 4;      // stream-K grid = up to g_oversub x resident workgroup slots
+int g_bf16 = 0;         // 1 = bf16 MFMA operands (fp32 accumulate) in the raw-window kernels
 
 int cu_count() { return pg_cu_count(); }
 
@@ -972,7 +1000,14 @@ bool raw_supported(Kind kind, const IgemmParams& p) {
 
 template <int KW, int S, bool TK>
 hipError_t launch_raw(const IgemmParams& p, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK>), dim3(grid), dim3(NT), 0, st, p);
+    if (g_bf16) hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, true>), dim3(grid), dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, false>), dim3(grid), dim3(NT), 0, st, p);
+    return hipGetLastError();
+}
+template <int KW, int S>
+hipError_t launch_g_raw(const IgemmParams& p, int grid, hipStream_t st) {
+    if (g_bf16) hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, true>), dim3(grid), dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, false>), dim3(grid), dim3(NT), 0, st, p);
     return hipGetLastError();
 }
 
@@ -996,11 +1031,10 @@ int launch(Kind kind, IgemmParams& p, long rows, long cols, long Ktot, long ws_b
         else if (p.s == 1) e = launch_raw<8, 1, true>(p, grid, st);
         else e = launch_raw<8, 2, true>(p, grid, st);
     } else if (raw) {
-        if (p.k == 32) hipLaunchKernelGGL((conv_g_raw_kernel<32, 2>), dim3(grid), dim3(NT), 0, st, p);
-        else if (p.k == 8 && p.s == 1) hipLaunchKernelGGL((conv_g_raw_kernel<8, 1>), dim3(grid), dim3(NT), 0, st, p);
-        else if (p.k == 8) hipLaunchKernelGGL((conv_g_raw_kernel<8, 2>), dim3(grid), dim3(NT), 0, st, p);
-        else hipLaunchKernelGGL((conv_g_raw_kernel<4, 2>), dim3(grid), dim3(NT), 0, st, p);
-        e = hipGetLastError();
+        if (p.k == 32) e = launch_g_raw<32, 2>(p, grid, st);
+        else if (p.k == 8 && p.s == 1) e = launch_g_raw<8, 1>(p, grid, st);
+        else if (p.k == 8) e = launch_g_raw<8, 2>(p, grid, st);
+        else e = launch_g_raw<4, 2>(p, grid, st);
     }
     else if (p.k == 32 && p.s == 2) e = launch_kind<32, 2>(kind, p, grid, st);
     else if (p.k == 8 && p.s == 1) e = launch_kind<8, 1>(kind, p, grid, st);
@@ -1167,6 +1201,12 @@ extern "C" int pg_conv_set_schedule(int mode) {
 // of the chip (RCCL's collective kernels during data-parallel backward), the workgroups that do not fit run as a second
 // wave and the launch takes up to twice as long.  factor > 1 splits the work over factor x more, proportionally shorter
 // workgroups, which bounds that tail at 1/factor of a workgroup's duration (at the price of more partial tiles).
+extern "C" int pg_conv_set_precision(int32_t mode) {
+    if (mode != 0 && mode != 1) return pg_fail(PG_ERR_UNSUPPORTED, "conv_set_precision: 0 (fp32) or 1 (bf16 operands)");
+    g_bf16 = mode;
+    return PG_OK;
+}
+
 extern "C" int pg_conv_set_oversubscribe(int factor) {
     if (factor < 1 || factor > 8) return pg_fail(PG_ERR_SHAPE, "conv_set_oversubscribe: factor must be 1..8");
     g_oversub = factor;

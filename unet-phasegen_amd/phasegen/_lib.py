@@ -90,6 +90,7 @@ SYMBOLS = {
     "pg_convt1d_wgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pg_workspace_bytes_conv": (C.c_int64, []),
     "pg_conv_set_schedule": (C.c_int, [C.c_int]),
+    "pg_conv_set_precision": (C.c_int, [C.c_int32]),
     "pg_conv_set_oversubscribe": (C.c_int, [C.c_int]),
     "pg_bn_fwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),
     "pg_bn_bwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),

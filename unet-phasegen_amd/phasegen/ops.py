@@ -100,6 +100,13 @@ def set_conv_oversubscribe(factor):
     _lib.check(_lib.load().pg_conv_set_oversubscribe(factor), "conv_set_oversubscribe")
 
 
+def set_conv_precision(mode):
+    """0 / "fp32": fp32 MFMA operands (the parity path, default).  1 / "bf16": operands rounded to bf16 at fragment
+    load, fp32 accumulate, fp32 tensors and master weights (BASELINE config 5)."""
+    mode = {"fp32": 0, "f32": 0, "bf16": 1}.get(mode, mode)
+    _lib.check(_lib.load().pg_conv_set_precision(int(mode)), "conv_set_precision")
+
+
 def set_stft_mode(single_frame):
     """0: 4 frames per workgroup through the half-length radix-4 real FFT (default); 1: one frame per workgroup, radix-2."""
     _lib.check(_lib.load().pg_stft_set_mode(int(bool(single_frame))), "stft_set_mode")
