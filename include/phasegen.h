@@ -60,8 +60,7 @@ int64_t pg_workspace_bytes_conv(void);
 int pg_conv_set_schedule(int mode);  /* test hook: bits 0-1: 0 auto, 1 one tile per workgroup, 2 force stream-K; bit 2: no raw-window kernels */
 /* Operand precision of the MFMA contraction (BASELINE config 5): 0 (default) = fp32 operands, v_mfma_f32_32x32x2_f32, the
  * 1e-4 parity path; 1 = operands rounded to bf16 (RNE, after the fused activation) at fragment load, v_mfma_f32_32x32x16_bf16,
- * fp32 accumulate -- tensors and master weights in HBM stay fp32.  Applies to the raw-window kernels (the k = 32 / 8 / 4
- * layers: 97 % of the step's FLOPs); layers on the im2col fallback stay fp32.  Process-wide. */
+ * fp32 accumulate -- tensors and master weights in HBM stay fp32.  Applies to every conv kernel.  Process-wide. */
 int pg_conv_set_precision(int32_t mode);
 int pg_conv_set_oversubscribe(int factor); /* stream-K grid = factor x resident slots (1..8); > 1 when other kernels (RCCL) share the chip */
 

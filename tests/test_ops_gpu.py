@@ -92,30 +92,23 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-BF16_GEOMS = [g for g in GEOMS if g[1] >= 64 and g[3] in (32, 8, 4)]
-STRICT = {(32, 2), (8, 1)}     # (k, s) whose three passes all run on the raw-window kernels at these sizes
-
-
-@pytest.mark.parametrize("geom", BF16_GEOMS)
+@pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("mode", [1, 2], ids=["tile-per-wg", "stream-k"])
+@pytest.mark.parametrize("mode", [1, 6], ids=["raw/tile-per-wg", "im2col/stream-k"])
 def test_conv_bf16_operand_mode(geom, act, mode):
     """pg_conv_set_precision(1) (BASELINE config 5): operands rounded to bf16 (RNE) AFTER the fused activation, fp32
-    accumulate.  Oracle = float64 autograd of the same conv on the rounded tensors, so only the accumulation order
-    differs: 2e-5.  Passes that stay on the fp32 im2col fallback must still meet the fp32 bound."""
+    accumulate, in every conv kernel.  Oracle = float64 autograd of the same conv on the rounded tensors, so only the
+    accumulation order differs: 2e-5 (against the unrounded fp32 oracle the same outputs are ~3e-3 off)."""
     from phasegen import ops
     tr, Cin, Cout, k, s, p, Lin, B = geom
     x = rnd(1, B, Cin, Lin)
     w = rnd(2, *((Cin, Cout, k) if tr else (Cout, Cin, k))) * 0.1
     conv = (lambda a, b: F.conv_transpose1d(a, b, stride=s, padding=p)) if tr else (lambda a, b: F.conv1d(a, b, stride=s, padding=p))
-    refs = {}
-    for name, r in (("bf16", bf16_round), ("fp32", lambda t: t)):
-        xa = r(act_cpu(x, act)).double().requires_grad_(True)
-        wr = r(w).double().requires_grad_(True)
-        yr = conv(xa, wr)
-        dy = rnd(3, *yr.shape)
-        yr.backward(r(dy).double())
-        refs[name] = (yr.detach(), xa.grad, wr.grad)
+    xa = bf16_round(act_cpu(x, act)).double().requires_grad_(True)
+    wr = bf16_round(w).double().requires_grad_(True)
+    yr = conv(xa, wr)
+    dy = rnd(3, *yr.shape)
+    yr.backward(bf16_round(dy).double())
     xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
     y, dx, dw = torch.empty(yr.shape, device="cuda"), torch.empty(x.shape, device="cuda"), torch.empty(w.shape, device="cuda")
     try:
@@ -127,14 +120,7 @@ def test_conv_bf16_operand_mode(geom, act, mode):
     finally:
         ops.set_conv_precision("fp32")
         ops.set_conv_schedule(0)
-    took_bf16 = 0
-    for got, i in ((y, 0), (dx, 1), (dw, 2)):
-        eb, ef = relerr(got, refs["bf16"][i]), relerr(got, refs["fp32"][i])
-        assert eb < 2e-5 or ef < 1e-5, (i, eb, ef)
-        took_bf16 += eb < 2e-5
-        if (k, s) in STRICT:
-            assert eb < 2e-5, (i, eb, ef)
-    assert took_bf16 >= 2 or k == 4          # the k4 layer at this small length stays on the fp32 im2col kernels
+    assert relerr(y, yr.detach()) < 2e-5 and relerr(dx, xa.grad) < 2e-5 and relerr(dw, wr.grad) < 2e-5
 
 
 def test_conv_on_concat_slices(schedule):

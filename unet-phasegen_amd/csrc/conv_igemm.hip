@@ -123,7 +123,36 @@ __device__ __forceinline__ void dma4(rsrc_t r, float* lds_wave_uniform, int byte
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 4, PG_ADDR(byte_off), 0, 0, 0);
 }
 
+// bf16 operand mode (pg_conv_set_precision(1)): the same fragments -- lane (row, h) already holds k = 8h .. 8h+7 of the
+// slab, which is exactly the operand layout of v_mfma_f32_32x32x16_bf16 -- are rounded to bf16 (RNE, v_cvt_pk_bf16_f32)
+// after the activation and one MFMA replaces eight; accumulation stays fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 to_bf16x8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    bf16x8 r;
+    r[0] = (__bf16)v0; r[1] = (__bf16)v1; r[2] = (__bf16)v2; r[3] = (__bf16)v3;
+    r[4] = (__bf16)v4; r[5] = (__bf16)v5; r[6] = (__bf16)v6; r[7] = (__bf16)v7;
+    return r;
+}
+__device__ __forceinline__ bf16x8 to_bf16x8(const f32x4 (&v)[2]) { return to_bf16x8(v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]); }
+__device__ __forceinline__ bf16x8 to_bf16x8(const float (&v)[8]) { return to_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]); }
+template <int MB, int NB>
+__device__ __forceinline__ void mfma_bf16(const bf16x8 (&A)[MB], const bf16x8 (&B)[NB], AccT<MB, NB>& acc) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc.c[i][j], 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_bf16_2x4(const f32x4 (&a)[2][2], const float (&b)[4][8], AccR& acc) {
+    bf16x8 A[2], B[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) A[i] = to_bf16x8(a[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) B[j] = to_bf16x8(b[j]);
+    mfma_bf16<2, 4>(A, B, acc);
+}
+
 // One BK=16 slab: (2*WMB + 4) x ds_read_b128 (swizzled), optional activation on the fragments, 8 k-pairs x 2*WMB MFMA.
+template <bool BF>
 __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs,
                                          int lane, int wm, int wn, float slopeA, float slopeB, Acc& acc) {
     const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
@@ -152,6 +181,15 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const flo
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) b[i][c][v] = act_apply(b[i][c][v], slopeB);
+    }
+    if (BF) {
+        bf16x8 A[WMB], B[2];
+#pragma unroll
+        for (int i = 0; i < WMB; ++i) A[i] = to_bf16x8(a[i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) B[j] = to_bf16x8(b[j]);
+        mfma_bf16<WMB, 2>(A, B, acc);
+        return;
     }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
@@ -331,7 +369,7 @@ __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const AccT<MB, 
               ISSUE }                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             PG_STAMP(1)                                                                             \
-            mma_slab(lds + cur * STAGE, lds + cur * STAGE + TILE_A, lane, wm, wn, slopeA, slopeB, acc); \
+            mma_slab<BF>(lds + cur * STAGE, lds + cur * STAGE + TILE_A, lane, wm, wn, slopeA, slopeB, acc); \
             __builtin_amdgcn_sched_barrier(0);                                                      \
             PG_STAMP(2)                                                                             \
             __syncthreads();                                                                        \
@@ -354,7 +392,7 @@ constexpr int FAR = (int)0x80000000u;
 // ------------------------------------------------------------------------------------------------------------
 // F kernel
 // ------------------------------------------------------------------------------------------------------------
-template <int KW, int S>
+template <int KW, int S, bool BF>
 __global__ __launch_bounds__(NT, 2) void conv_f_kernel(const IgemmParams p) {
     const int Ktot = p.Q * (KW ? KW : p.k), Ntot = p.B * p.Ly;
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
@@ -397,7 +435,7 @@ __global__ __launch_bounds__(NT, 2) void conv_f_kernel(const IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------
 // T kernel.  GEMM rows m' = o*s + phi, K = (q, jj) with KJ = ceil(k/s) taps per phase, N = (b, u).
 // ------------------------------------------------------------------------------------------------------------
-template <int KW, int S>
+template <int KW, int S, bool BF>
 __global__ __launch_bounds__(NT, 2) void conv_t_kernel(const IgemmParams p) {
     const int kw_ = KW ? KW : p.k, s_ = S ? S : p.s;
     const int KJ = (kw_ + s_ - 1) / s_;
@@ -447,7 +485,7 @@ __device__ __forceinline__ void divmod24(int n, int d, float inv, int& q, int& r
     if (r >= d) { r -= d; ++q; }
 }
 
-template <int KW, int S>
+template <int KW, int S, bool BF>
 __global__ __launch_bounds__(NT, 2) void conv_g_kernel(const IgemmParams p) {
     const int Ntot = p.Q * (KW ? KW : p.k);
     const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
@@ -536,28 +574,6 @@ __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, con
 #pragma unroll
             for (int i = 0; i < 8; ++i) f.b[jb][i] = act_apply(f.b[jb][i], slopeB);
     }
-}
-
-// bf16 operand mode (pg_conv_set_precision(1)): the same fragments -- lane (row, h) already holds k = 8h .. 8h+7 of the
-// slab, which is exactly the operand layout of v_mfma_f32_32x32x16_bf16 -- are rounded to bf16 (RNE, v_cvt_pk_bf16_f32)
-// after the activation and one MFMA replaces eight; accumulation stays fp32.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ bf16x8 to_bf16x8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
-    bf16x8 r;
-    r[0] = (__bf16)v0; r[1] = (__bf16)v1; r[2] = (__bf16)v2; r[3] = (__bf16)v3;
-    r[4] = (__bf16)v4; r[5] = (__bf16)v5; r[6] = (__bf16)v6; r[7] = (__bf16)v7;
-    return r;
-}
-__device__ __forceinline__ void mfma_bf16_2x4(const f32x4 (&a)[2][2], const float (&b)[4][8], AccR& acc) {
-    bf16x8 A[2], B[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) A[i] = to_bf16x8(a[i][0][0], a[i][0][1], a[i][0][2], a[i][0][3], a[i][1][0], a[i][1][1], a[i][1][2], a[i][1][3]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) B[j] = to_bf16x8(b[j][0], b[j][1], b[j][2], b[j][3], b[j][4], b[j][5], b[j][6], b[j][7]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc.c[i][j], 0, 0, 0);
 }
 
 template <bool BF>
@@ -934,13 +950,19 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
 // host side
 // ------------------------------------------------------------------------------------------------------------
 enum Kind { KIND_F, KIND_T, KIND_G };
+int g_bf16 = 0;         // 1 = bf16 MFMA operands (fp32 accumulate): pg_conv_set_precision
 
 template <int KW, int S>
 hipError_t launch_kind(Kind kind, const IgemmParams& p, int grid, hipStream_t st) {
-    switch (kind) {
-        case KIND_F: hipLaunchKernelGGL((conv_f_kernel<KW, S>), dim3(grid), dim3(NT), 0, st, p); break;
-        case KIND_T: hipLaunchKernelGGL((conv_t_kernel<KW, S>), dim3(grid), dim3(NT), 0, st, p); break;
-        case KIND_G: hipLaunchKernelGGL((conv_g_kernel<KW, S>), dim3(grid), dim3(NT), 0, st, p); break;
+    if (g_bf16) switch (kind) {
+        case KIND_F: hipLaunchKernelGGL((conv_f_kernel<KW, S, true>), dim3(grid), dim3(NT), 0, st, p); break;
+        case KIND_T: hipLaunchKernelGGL((conv_t_kernel<KW, S, true>), dim3(grid), dim3(NT), 0, st, p); break;
+        case KIND_G: hipLaunchKernelGGL((conv_g_kernel<KW, S, true>), dim3(grid), dim3(NT), 0, st, p); break;
+    }
+    else switch (kind) {
+        case KIND_F: hipLaunchKernelGGL((conv_f_kernel<KW, S, false>), dim3(grid), dim3(NT), 0, st, p); break;
+        case KIND_T: hipLaunchKernelGGL((conv_t_kernel<KW, S, false>), dim3(grid), dim3(NT), 0, st, p); break;
+        case KIND_G: hipLaunchKernelGGL((conv_g_kernel<KW, S, false>), dim3(grid), dim3(NT), 0, st, p); break;
     }
     return hipGetLastError();
 }
@@ -953,7 +975,6 @@ constexpr long WS_PER_WG = 2L * ACC_REGS * NT * 4;   // two partial tiles of 256
 int g_force_mode = 0;   // work split: 0 automatic, 1 one tile per workgroup, 2 force stream-K
 int g_force_raw = 0;    // 1 = never use the raw-window kernels (exercise the im2col kernels)
 int g_oversub = 4;      // stream-K grid = up to g_oversub x resident workgroup slots
-int g_bf16 = 0;         // 1 = bf16 MFMA operands (fp32 accumulate) in the raw-window kernels
 
 int cu_count() { return pg_cu_count(); }
 
