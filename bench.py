@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--channels", type=int, default=1024, help="C (bins); 1024 = the reference's hard-coded model")
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
                     help="MFMA operand precision: fp32 = the parity path and the headline; bf16 = BASELINE configs[4]'s arithmetic "
                          "(bf16 operands, fp32 accumulate, fp32 tensors and master weights) -- reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,7 +182,8 @@ def main():
             "metric": "spectrogram-frames/sec (train fwd+bwd)", "value": frames / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "fp32" else "bf16 operands / f32 accumulate", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate",
+                      "bf16x3": "f32 operands split hi+lo into 3 bf16 MFMA products / f32 accumulate"}[a.precision], "data": "synthetic",
             "config": {"workload": f"train.py full step (fwd + cos/sin/mag loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}), "
                                    f"UNetModel({C}, {2 * C}), per-GPU batch {B} x {C} bins x {L} frames (BASELINE configs[2]{'/[3]' if world > 1 else ''})",
                        "global_batch": world * B, "frames": L, "channels": C, "parallelism": f"dp{world}",

@@ -60,7 +60,10 @@ int64_t pg_workspace_bytes_conv(void);
 int pg_conv_set_schedule(int mode);  /* test hook: bits 0-1: 0 auto, 1 one tile per workgroup, 2 force stream-K; bit 2: no raw-window kernels */
 /* Operand precision of the MFMA contraction (BASELINE config 5): 0 (default) = fp32 operands, v_mfma_f32_32x32x2_f32, the
  * 1e-4 parity path; 1 = operands rounded to bf16 (RNE, after the fused activation) at fragment load, v_mfma_f32_32x32x16_bf16,
- * fp32 accumulate -- tensors and master weights in HBM stay fp32.  Applies to every conv kernel.  Process-wide. */
+ * fp32 accumulate -- tensors and master weights in HBM stay fp32; 2 = "bf16x3": every fp32 operand is split exactly into
+ * hi + lo bf16 parts and each product is taken as hi*hi' + hi*lo' + lo*hi' on the bf16 pipe (three MFMAs at 1/16 of the fp32
+ * cost; ~5e-6 from exact against fp32 MFMA's ~1e-6: inside the 1e-4 parity bound, not fp32).  Applies to every conv kernel.
+ * Process-wide.  Environment: PHASEGEN_CONV_PRECISION=fp32|bf16|bf16x3 sets it when the Python host loads the library. */
 int pg_conv_set_precision(int32_t mode);
 int pg_conv_set_oversubscribe(int factor); /* stream-K grid = factor x resident slots (1..8); > 1 when other kernels (RCCL) share the chip */
 

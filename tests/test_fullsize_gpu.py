@@ -47,6 +47,18 @@ def test_conv_layer_at_full_size_bf16_operands(layer):
         ops.set_conv_precision("fp32")
 
 
+@pytest.mark.parametrize("layer", [LAYERS[0], LAYERS[2], LAYERS[4], LAYERS[7]], ids=["D0", "D2", "U3", "U0"])
+def test_conv_layer_at_full_size_bf16x3_split(layer):
+    """pg_conv_set_precision(2) at the real geometry: the same float64 spot values (UNROUNDED operands, 1e-4 of max-abs)
+    and adjoint identities as the fp32 path."""
+    from phasegen import ops
+    ops.set_conv_precision("bf16x3")
+    try:
+        check_layer(layer, bf16=False)
+    finally:
+        ops.set_conv_precision("fp32")
+
+
 def check_layer(layer, bf16):
     from phasegen import ops
     name, tr, Cin, Cout, k, s, p, Lin, act = layer

@@ -123,6 +123,37 @@ def test_conv_bf16_operand_mode(geom, act, mode):
     assert relerr(y, yr.detach()) < 2e-5 and relerr(dx, xa.grad) < 2e-5 and relerr(dw, wr.grad) < 2e-5
 
 
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("mode", [1, 6], ids=["raw/tile-per-wg", "im2col/stream-k"])
+def test_conv_bf16x3_split_mode_meets_the_fp32_bound(geom, mode):
+    """pg_conv_set_precision(2): fp32 operands split hi + lo into bf16 pairs, three bf16 MFMA products, fp32 accumulate.
+    Checked against the UNROUNDED float64 convolution: the dropped lo*lo term and the split residuals are <= 2^-18 of a
+    product, so the result sits ~5e-6 from exact -- 20x inside the 1e-4 parity bound (fp32 MFMA: ~1e-6)."""
+    from phasegen import ops
+    tr, Cin, Cout, k, s, p, Lin, B = geom
+    act = 1
+    x = rnd(1, B, Cin, Lin)
+    w = rnd(2, *((Cin, Cout, k) if tr else (Cout, Cin, k))) * 0.1
+    xa = act_cpu(x, act).double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = F.conv_transpose1d(xa, wr, stride=s, padding=p) if tr else F.conv1d(xa, wr, stride=s, padding=p)
+    dy = rnd(3, *yr.shape)
+    yr.backward(dy.double())
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    y, dx, dw = torch.empty(yr.shape, device="cuda"), torch.empty(x.shape, device="cuda"), torch.empty(w.shape, device="cuda")
+    try:
+        ops.set_conv_schedule(mode)
+        ops.set_conv_precision("bf16x3")
+        ops.conv_fwd(xd, wd, y, s, p, x_act=act, transposed=tr)
+        ops.conv_dgrad(dyd, wd, dx, s, p, transposed=tr)
+        ops.conv_wgrad(xd, dyd, dw, s, p, x_act=act, transposed=tr)
+    finally:
+        ops.set_conv_precision("fp32")
+        ops.set_conv_schedule(0)
+    errs = relerr(y, yr.detach()), relerr(dx, xa.grad), relerr(dw, wr.grad)
+    assert max(errs) < 2e-5, errs
+
+
 def test_conv_on_concat_slices(schedule):
     """Operands given as channel slices of a wider buffer (batch stride != C*L), as the U-Net concat does."""
     from phasegen import ops

@@ -63,6 +63,32 @@ def test_forward_backward_vs_reference_golden(case, golden_dir):
         assert rel(eng.arena.buffers[k + ".running_var"], gold["stat/" + k + ".running_var"]) < TOL_F
 
 
+@pytest.mark.parametrize("case", [(16, 128, 2), (8, 64, 3)])
+def test_golden_parity_also_holds_in_bf16x3_split_mode(case, golden_dir):
+    """The reference goldens at the SAME tolerances with pg_conv_set_precision(2) (three bf16 MFMA products per fp32
+    product, ~5e-6 per conv): forward tensors 1e-4, gradients 5e-4."""
+    from phasegen import ops
+    C, L, B = case
+    gold = np.load(os.path.join(golden_dir, f"unet_C{C}_L{L}_B{B}.npz"))
+    ops.set_conv_precision("bf16x3")
+    try:
+        m = make_model(C)
+        eng = m.engine
+        batch = torch.from_numpy(detgen.make_batch(B, C, L, seed=1)).cuda()
+        out = eng.forward(batch[:, 0])
+        assert rel(out, gold["out"]) < TOL_F
+        for k, v in eng.intermediates().items():
+            assert rel(v, activated(gold, k)) < TOL_F, k
+        dpred = torch.empty_like(out)
+        losses = ops.loss_fwd_bwd(out, batch, dpred)
+        assert np.allclose(losses.cpu().numpy(), gold["loss"], rtol=2e-5)
+        eng.backward(dpred)
+        for k in detgen.param_order():
+            assert rel(eng.arena.g(k), gold["grad/" + k]) < TOL_G, k
+    finally:
+        ops.set_conv_precision("fp32")
+
+
 def test_three_adam_steps_vs_reference_golden(golden_dir):
     from phasegen.trainer import Trainer
     C, L, B = 8, 64, 3

@@ -20,12 +20,16 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--stamps", action="store_true")
 ap.add_argument("--act", type=int, default=2)
 ap.add_argument("--precision", default="fp32")
+ap.add_argument("--schedule", type=int, default=0)
+ap.add_argument("--oversub", type=int, default=4)
 a = ap.parse_args()
 if a.lib:
     from phasegen import _lib
     _lib.LIB_PATH = os.path.abspath(a.lib)
 C, L, B = 1024, 256, a.batch
 ops.set_conv_precision(a.precision)
+ops.set_conv_schedule(a.schedule)
+ops.set_conv_oversubscribe(a.oversub)
 L1, L2, L3, L4 = frame_plan(L)
 geo = {"D0": (C, 2 * C, 32, L), "D1": (2 * C, 2 * C, 8, L1), "D2": (2 * C, 2 * C, 8, L2), "D3": (2 * C, 4 * C, 4, L3),
        "U3": (4 * C, 2 * C, 5, L4), "U2": (4 * C, 2 * C, 8, L3), "U1": (4 * C, 2 * C, 8, L2), "U0": (4 * C, 2 * C, 32, L1)}

@@ -142,17 +142,56 @@ __device__ __forceinline__ void mfma_bf16(const bf16x8 (&A)[MB], const bf16x8 (&
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc.c[i][j], 0, 0, 0);
 }
-__device__ __forceinline__ void mfma_bf16_2x4(const f32x4 (&a)[2][2], const float (&b)[4][8], AccR& acc) {
-    bf16x8 A[2], B[4];
+// Split mode (pg_conv_set_precision(2), "bf16x3"): every fp32 operand is written as hi + lo with hi = bf16(x) and
+// lo = bf16(x - hi) (the subtraction is exact), and the product is taken as hi*hi' + hi*lo' + lo*hi' on the bf16 pipe:
+// three MFMAs at 1/16 of the fp32 cost each.  Dropped: lo*lo' and the two representation residuals, each <= 2^-18 of the
+// product, i.e. a relative error of ~1e-5 per product against fp32's 6e-8 -- inside the 1e-4 parity bound, NOT fp32.
+__device__ __forceinline__ void split_bf16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) A[i] = to_bf16x8(a[i]);
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(v[i] - (float)h);
+    }
+}
+template <int PM, int MB, int NB>
+__device__ __forceinline__ void mfma_low(const float (&a)[MB][8], const float (&b)[NB][8], AccT<MB, NB>& acc) {
+    if (PM == 1) {
+        bf16x8 A[MB], B[NB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) B[j] = to_bf16x8(b[j]);
-    mfma_bf16<2, 4>(A, B, acc);
+        for (int i = 0; i < MB; ++i) A[i] = to_bf16x8(a[i]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) B[j] = to_bf16x8(b[j]);
+        mfma_bf16<MB, NB>(A, B, acc);
+    } else {
+        bf16x8 Ah[MB], Al[MB], Bh[NB], Bl[NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) split_bf16(a[i], Ah[i], Al[i]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) split_bf16(b[j], Bh[j], Bl[j]);
+        mfma_bf16<MB, NB>(Al, Bh, acc);          // small terms first
+        mfma_bf16<MB, NB>(Ah, Bl, acc);
+        mfma_bf16<MB, NB>(Ah, Bh, acc);
+    }
+}
+template <int N>
+__device__ __forceinline__ void flatten(const f32x4 (&v)[N][2], float (&o)[N][8]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[i][4 * c + e] = v[i][c][e];
+}
+template <int PM>
+__device__ __forceinline__ void mfma_low_2x4(const f32x4 (&a)[2][2], const float (&b)[4][8], AccR& acc) {
+    float af[2][8];
+    flatten<2>(a, af);
+    mfma_low<PM, 2, 4>(af, b, acc);
 }
 
 // One BK=16 slab: (2*WMB + 4) x ds_read_b128 (swizzled), optional activation on the fragments, 8 k-pairs x 2*WMB MFMA.
-template <bool BF>
+template <int BF>
 __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs,
                                          int lane, int wm, int wn, float slopeA, float slopeB, Acc& acc) {
     const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
@@ -183,12 +222,10 @@ __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const flo
                 for (int v = 0; v < 4; ++v) b[i][c][v] = act_apply(b[i][c][v], slopeB);
     }
     if (BF) {
-        bf16x8 A[WMB], B[2];
-#pragma unroll
-        for (int i = 0; i < WMB; ++i) A[i] = to_bf16x8(a[i]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) B[j] = to_bf16x8(b[j]);
-        mfma_bf16<WMB, 2>(A, B, acc);
+        float af[WMB][8], bf[2][8];
+        flatten<WMB>(a, af);
+        flatten<2>(b, bf);
+        mfma_low<BF, WMB, 2>(af, bf, acc);
         return;
     }
 #pragma unroll
@@ -392,7 +429,7 @@ constexpr int FAR = (int)0x80000000u;
 // ------------------------------------------------------------------------------------------------------------
 // F kernel
 // ------------------------------------------------------------------------------------------------------------
-template <int KW, int S, bool BF>
+template <int KW, int S, int BF>
 __global__ __launch_bounds__(NT, 2) void conv_f_kernel(const IgemmParams p) {
     const int Ktot = p.Q * (KW ? KW : p.k), Ntot = p.B * p.Ly;
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
@@ -435,7 +472,7 @@ __global__ __launch_bounds__(NT, 2) void conv_f_kernel(const IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------
 // T kernel.  GEMM rows m' = o*s + phi, K = (q, jj) with KJ = ceil(k/s) taps per phase, N = (b, u).
 // ------------------------------------------------------------------------------------------------------------
-template <int KW, int S, bool BF>
+template <int KW, int S, int BF>
 __global__ __launch_bounds__(NT, 2) void conv_t_kernel(const IgemmParams p) {
     const int kw_ = KW ? KW : p.k, s_ = S ? S : p.s;
     const int KJ = (kw_ + s_ - 1) / s_;
@@ -485,7 +522,7 @@ __device__ __forceinline__ void divmod24(int n, int d, float inv, int& q, int& r
     if (r >= d) { r -= d; ++q; }
 }
 
-template <int KW, int S, bool BF>
+template <int KW, int S, int BF>
 __global__ __launch_bounds__(NT, 2) void conv_g_kernel(const IgemmParams p) {
     const int Ntot = p.Q * (KW ? KW : p.k);
     const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
@@ -576,9 +613,9 @@ __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, con
     }
 }
 
-template <bool BF>
+template <int BF>
 __device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
-    if (BF) { mfma_bf16_2x4(f.a, f.b, acc); return; }
+    if (BF) { mfma_low_2x4<BF>(f.a, f.b, acc); return; }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
@@ -588,7 +625,7 @@ __device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
                 acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk >> 2][kk & 3], f.b[j][kk], acc.c[i][j], 0, 0, 0);
 }
 
-template <int TJ, bool DESC, int RS, bool BF>
+template <int TJ, bool DESC, int RS, int BF>
 __device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
                                              const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
     RawFrags f;
@@ -598,7 +635,7 @@ __device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const
 
 // TKIND false: F (conv fwd / convT dgrad, taps ascend with stride s between columns)
 // TKIND true : T (convT fwd / conv dgrad in gather form, unit column stride, taps descend)
-template <int KW, int S, bool TKIND, bool BF>
+template <int KW, int S, bool TKIND, int BF>
 __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
     constexpr int TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ;
@@ -765,7 +802,7 @@ template <int KW, int S> struct GRaw {
     static_assert(WL <= WLP, "window does not fit its slot");
 };
 
-template <int KW, int S, bool BF>
+template <int KW, int S, int BF>
 __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) {
     using C = GRaw<KW, S>;
     __shared__ __attribute__((aligned(16))) float lds[2 * C::STG];
@@ -891,7 +928,7 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
 #pragma unroll
                         for (int i = 0; i < 8; ++i) b[jb][i] = act_apply(b[jb][i], slopeB);
                 }
-                if (BF) mfma_bf16_2x4(a, b, acc);
+                if (BF) mfma_low_2x4<BF>(a, b, acc);
                 else {
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk)
@@ -950,20 +987,18 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
 // host side
 // ------------------------------------------------------------------------------------------------------------
 enum Kind { KIND_F, KIND_T, KIND_G };
-int g_bf16 = 0;         // 1 = bf16 MFMA operands (fp32 accumulate): pg_conv_set_precision
+int g_bf16 = 0;         // pg_conv_set_precision: 0 fp32 MFMA, 1 bf16 operands, 2 bf16x3 split (all fp32 accumulate)
 
 template <int KW, int S>
 hipError_t launch_kind(Kind kind, const IgemmParams& p, int grid, hipStream_t st) {
-    if (g_bf16) switch (kind) {
-        case KIND_F: hipLaunchKernelGGL((conv_f_kernel<KW, S, true>), dim3(grid), dim3(NT), 0, st, p); break;
-        case KIND_T: hipLaunchKernelGGL((conv_t_kernel<KW, S, true>), dim3(grid), dim3(NT), 0, st, p); break;
-        case KIND_G: hipLaunchKernelGGL((conv_g_kernel<KW, S, true>), dim3(grid), dim3(NT), 0, st, p); break;
+#define PG_LAUNCH_KIND(PM)                                                                                      \
+    switch (kind) {                                                                                             \
+        case KIND_F: hipLaunchKernelGGL((conv_f_kernel<KW, S, PM>), dim3(grid), dim3(NT), 0, st, p); break;     \
+        case KIND_T: hipLaunchKernelGGL((conv_t_kernel<KW, S, PM>), dim3(grid), dim3(NT), 0, st, p); break;     \
+        case KIND_G: hipLaunchKernelGGL((conv_g_kernel<KW, S, PM>), dim3(grid), dim3(NT), 0, st, p); break;     \
     }
-    else switch (kind) {
-        case KIND_F: hipLaunchKernelGGL((conv_f_kernel<KW, S, false>), dim3(grid), dim3(NT), 0, st, p); break;
-        case KIND_T: hipLaunchKernelGGL((conv_t_kernel<KW, S, false>), dim3(grid), dim3(NT), 0, st, p); break;
-        case KIND_G: hipLaunchKernelGGL((conv_g_kernel<KW, S, false>), dim3(grid), dim3(NT), 0, st, p); break;
-    }
+    if (g_bf16 == 1) { PG_LAUNCH_KIND(1) } else if (g_bf16 == 2) { PG_LAUNCH_KIND(2) } else { PG_LAUNCH_KIND(0) }
+#undef PG_LAUNCH_KIND
     return hipGetLastError();
 }
 
@@ -1021,14 +1056,16 @@ bool raw_supported(Kind kind, const IgemmParams& p) {
 
 template <int KW, int S, bool TK>
 hipError_t launch_raw(const IgemmParams& p, int grid, hipStream_t st) {
-    if (g_bf16) hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, true>), dim3(grid), dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, false>), dim3(grid), dim3(NT), 0, st, p);
+    if (g_bf16 == 1) hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, 1>), dim3(grid), dim3(NT), 0, st, p);
+    else if (g_bf16 == 2) hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, 2>), dim3(grid), dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, 0>), dim3(grid), dim3(NT), 0, st, p);
     return hipGetLastError();
 }
 template <int KW, int S>
 hipError_t launch_g_raw(const IgemmParams& p, int grid, hipStream_t st) {
-    if (g_bf16) hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, true>), dim3(grid), dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, false>), dim3(grid), dim3(NT), 0, st, p);
+    if (g_bf16 == 1) hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, 1>), dim3(grid), dim3(NT), 0, st, p);
+    else if (g_bf16 == 2) hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, 2>), dim3(grid), dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, 0>), dim3(grid), dim3(NT), 0, st, p);
     return hipGetLastError();
 }
 
@@ -1223,7 +1260,7 @@ extern "C" int pg_conv_set_schedule(int mode) {
 // wave and the launch takes up to twice as long.  factor > 1 splits the work over factor x more, proportionally shorter
 // workgroups, which bounds that tail at 1/factor of a workgroup's duration (at the price of more partial tiles).
 extern "C" int pg_conv_set_precision(int32_t mode) {
-    if (mode != 0 && mode != 1) return pg_fail(PG_ERR_UNSUPPORTED, "conv_set_precision: 0 (fp32) or 1 (bf16 operands)");
+    if (mode < 0 || mode > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv_set_precision: 0 (fp32), 1 (bf16 operands) or 2 (bf16x3 split)");
     g_bf16 = mode;
     return PG_OK;
 }

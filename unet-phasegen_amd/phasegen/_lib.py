@@ -128,6 +128,13 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # PHASEGEN_CONV_PRECISION=fp32|bf16|bf16x3 selects the MFMA operand mode at load (pg_conv_set_precision; default fp32)
+    mode = os.environ.get("PHASEGEN_CONV_PRECISION")
+    if mode:
+        modes = {"fp32": 0, "bf16": 1, "bf16x3": 2}
+        if mode not in modes:
+            raise RuntimeError(f"PHASEGEN_CONV_PRECISION={mode!r}: expected one of {sorted(modes)}")
+        check(lib.pg_conv_set_precision(modes[mode]), "conv_set_precision")
     return lib
 
 

@@ -103,7 +103,7 @@ def set_conv_oversubscribe(factor):
 def set_conv_precision(mode):
     """0 / "fp32": fp32 MFMA operands (the parity path, default).  1 / "bf16": operands rounded to bf16 at fragment
     load, fp32 accumulate, fp32 tensors and master weights (BASELINE config 5)."""
-    mode = {"fp32": 0, "f32": 0, "bf16": 1}.get(mode, mode)
+    mode = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}.get(mode, mode)
     _lib.check(_lib.load().pg_conv_set_precision(int(mode)), "conv_set_precision")
 
 
