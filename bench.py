@@ -13,6 +13,10 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
   cpu_baseline the oracle (CPU restatement of the reference, oracle/unet_ref.py) doing the SAME training step on the
                host cores on a bounded sample (batch 16 of the same C=1024, L=256 model); rank 0, N = 1 only.
   kernels      per-layer conv timings (ms, TFLOP/s) for DESIGN.md's table.
+  other_precisions  (N = 1, default fp32 run only) the same step re-timed for 5 steps in the two optional MFMA operand modes
+               (pg_conv_set_precision): "bf16x3" = fp32 operands split into hi + lo bf16, 3 bf16 MFMA products (~5e-6 from
+               exact, passes the golden parity suite) and "bf16" = operands rounded to bf16 (BASELINE configs[4]).  Reported
+               beside the headline, never as `value`.
 """
 import argparse
 import json
@@ -112,6 +116,7 @@ def main():
                     help="MFMA operand precision: fp32 = the parity path and the headline; bf16 = BASELINE configs[4]'s arithmetic "
                          "(bf16 operands, fp32 accumulate, fp32 tensors and master weights) -- reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-precisions", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None)
     a = ap.parse_args()
 
@@ -197,6 +202,22 @@ def main():
                          "step_tflops": round((3 * sum(fl.values()) - fl["D0"]) / (dt / a.steps) / 1e12, 2)},
             "kernels": ks,
         }
+        if world == 1 and a.precision == "fp32" and not a.no_other_precisions:
+            other = {}
+            for mode in ("bf16x3", "bf16"):
+                ops.set_conv_precision(mode)
+                for _ in range(2):
+                    trainer.step(batch)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    trainer.step(batch)
+                torch.cuda.synchronize()
+                d1 = (time.perf_counter() - t1) / 5
+                other[mode] = {"ms_per_step": d1 * 1e3, "frames_per_s": B * L / d1,
+                               "step_tflops": round((3 * sum(fl.values()) - fl["D0"]) / d1 / 1e12, 2)}
+            ops.set_conv_precision("fp32")
+            out["other_precisions"] = other
         if world == 1 and not a.no_cpu_baseline and a.precision == "fp32":
             del trainer, model, batch
             torch.cuda.empty_cache()
