@@ -146,13 +146,23 @@ __device__ __forceinline__ void mfma_bf16(const bf16x8 (&A)[MB], const bf16x8 (&
 // lo = bf16(x - hi) (the subtraction is exact), and the product is taken as hi*hi' + hi*lo' + lo*hi' on the bf16 pipe:
 // three MFMAs at 1/16 of the fp32 cost each.  Dropped: lo*lo' and the two representation residuals, each <= 2^-18 of the
 // product, i.e. a relative error of ~1e-5 per product against fp32's 6e-8 -- inside the 1e-4 parity bound, NOT fp32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_bf16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    u32x4 H, L;                                      // pairwise: one v_cvt_pk per two values, shifts/masks to widen hi back
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)v[i];
-        hi[i] = h;
-        lo[i] = (__bf16)(v[i] - (float)h);
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 x = {v[2 * i], v[2 * i + 1]};
+        const bf16x2 h = __builtin_convertvector(x, bf16x2);
+        const unsigned P = __builtin_bit_cast(unsigned, h);
+        const f32x2 hf = {__uint_as_float(P << 16), __uint_as_float(P & 0xffff0000u)};
+        const bf16x2 l = __builtin_convertvector(x - hf, bf16x2);
+        H[i] = P;
+        L[i] = __builtin_bit_cast(unsigned, l);
     }
+    hi = __builtin_bit_cast(bf16x8, H);
+    lo = __builtin_bit_cast(bf16x8, L);
 }
 template <int PM, int MB, int NB>
 __device__ __forceinline__ void mfma_low(const float (&a)[MB][8], const float (&b)[NB][8], AccT<MB, NB>& acc) {
