@@ -174,14 +174,29 @@ __device__ __forceinline__ void mfma_low(const float (&a)[MB][8], const float (&
         for (int j = 0; j < NB; ++j) B[j] = to_bf16x8(b[j]);
         mfma_bf16<MB, NB>(A, B, acc);
     } else {
-        bf16x8 Ah[MB], Al[MB], Bh[NB], Bl[NB];
+        // column block by column block, so the split of block j+1 (VALU) can run under the six MFMAs of block j; the same
+        // accumulator is touched every MB MFMAs (small terms first)
+        bf16x8 Ah[MB], Al[MB], Bh[2], Bl[2];
 #pragma unroll
         for (int i = 0; i < MB; ++i) split_bf16(a[i], Ah[i], Al[i]);
+        split_bf16(b[0], Bh[0], Bl[0]);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) split_bf16(b[j], Bh[j], Bl[j]);
-        mfma_bf16<MB, NB>(Al, Bh, acc);          // small terms first
-        mfma_bf16<MB, NB>(Ah, Bl, acc);
-        mfma_bf16<MB, NB>(Ah, Bh, acc);
+        for (int j = 0; j < NB; ++j) {
+            if (j + 1 < NB) split_bf16(b[j + 1], Bh[(j + 1) & 1], Bl[(j + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[i], Bh[j & 1], acc.c[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bl[j & 1], acc.c[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[i], Bh[j & 1], acc.c[i][j], 0, 0, 0);
+            if (j + 1 < NB) {
+#pragma unroll
+                for (int g = 0; g < 3 * MB; ++g) {       // interleave: one MFMA, then a slice of the next block's split
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (21 + 3 * MB - 1) / (3 * MB), 0);
+                }
+            }
+        }
     }
 }
 template <int N>
