@@ -50,3 +50,19 @@ def test_train_then_demo(tmp_path):
         assert sr == 16000 and a.dtype == np.float32 and a.shape == (hop * (L - 1),) and abs(np.max(np.abs(a)) - 1) < 1e-5
         sr, gl = wavfile.read(tmp_path / "demo" / f"gl_Pop_{c}.wav")                  # demo.py:58 Griffin-Lim comparator
         assert gl.shape == a.shape and abs(np.max(np.abs(gl)) - 1) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_train_accepts_the_precision_modes(tmp_path, precision):
+    """--precision selects the MFMA operand mode (pg_conv_set_precision) for the whole run; the losses of the first
+    steps stay close to the fp32 run's (same synthetic clips, same initialisation)."""
+    import re
+    args = [os.path.join(PKG, "train.py"), "--channels", "16", "--batch_size", "2", "--max_steps", "3", "--synthetic", "4",
+            "--frames", "24", "--val_every", "1000", "--ckpt_every", "1000", "--log_dir", "run/"]
+    ref = run(args, cwd=str(tmp_path))
+    got = run(args + ["--precision", precision], cwd=str(tmp_path))
+    pat = re.compile(r"mag loss: ([0-9.eE+-]+)")
+    a, b = [float(x) for x in pat.findall(ref)], [float(x) for x in pat.findall(got)]
+    assert len(a) == len(b) > 0
+    tol = 1e-4 if precision == "bf16x3" else 3e-2
+    assert np.allclose(a, b, rtol=tol), (a, b)

@@ -27,6 +27,8 @@ def main():
     parser.add_argument("--channels", default=1024, type=int, help="bins = model width (reference hard-codes 1024)")
     parser.add_argument("--dataset_dir", default="dataset")
     parser.add_argument("--out_dir", default="demo")
+    parser.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
+                    help="MFMA operand mode of the convolutions (pg_conv_set_precision): fp32 = the reference's arithmetic")
     args = parser.parse_args()
 
     import numpy as np
@@ -34,6 +36,8 @@ def main():
     from scipy.io import wavfile
     from data import get_fft_npy_loader
     from utils import generate_audio
+    from phasegen import ops as _ops
+    _ops.set_conv_precision(args.precision)
     from cycleGAN import UNetModel
     from phasegen import audio as pg_audio
 

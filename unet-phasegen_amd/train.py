@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--resume", default=None, help="checkpoint written by a previous run (ckpt_N + ckpt_N.optim)")
     ap.add_argument("--synthetic", type=int, default=0, help="train on N synthetic clips instead of --train (no dataset ships)")
     ap.add_argument("--frames", type=int, default=128, help="frames per synthetic clip")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
+                    help="MFMA operand mode of the convolutions (pg_conv_set_precision): fp32 = the reference's arithmetic")
     a = ap.parse_args()
 
     import numpy as np
@@ -48,6 +50,8 @@ def main():
     import torch.distributed as dist
     from phasegen import detgen
     from phasegen.data import SpectrogramLoader, get_fft_npy_loader
+    from phasegen import ops as _ops
+    _ops.set_conv_precision(a.precision)
     from phasegen.model import UNetModel
     from phasegen.trainer import Trainer
     from phasegen.validate import validation_metrics
