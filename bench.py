@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
                     help="MFMA operand precision: fp32 = the parity path and the headline; bf16 = BASELINE configs[4]'s arithmetic "
                          "(bf16 operands, fp32 accumulate, fp32 tensors and master weights) -- reported separately")
+    ap.add_argument("--grad-compress", choices=["none", "bf16"], default="none",
+                    help="N > 1: payload of the gradient all-reduce (bf16 halves the xGMI bytes; default fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None)
@@ -146,7 +148,7 @@ def main():
     peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     torch.manual_seed(0)
     model = UNetModel(C, 2 * C, gpu_ids=[local])
-    trainer = Trainer(model, lr=1e-3)
+    trainer = Trainer(model, lr=1e-3, grad_compress=None if a.grad_compress == "none" else a.grad_compress)
     gen = torch.Generator(device="cuda").manual_seed(1 + rank)
     re = torch.randn(B, C, L, device="cuda", generator=gen)
     im = torch.randn(B, C, L, device="cuda", generator=gen)
@@ -192,6 +194,7 @@ def main():
             "config": {"workload": f"train.py full step (fwd + cos/sin/mag loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}), "
                                    f"UNetModel({C}, {2 * C}), per-GPU batch {B} x {C} bins x {L} frames (BASELINE configs[2]{'/[3]' if world > 1 else ''})",
                        "global_batch": world * B, "frames": L, "channels": C, "parallelism": f"dp{world}",
+                       "grad_allreduce_payload": "fp32" if a.grad_compress == "none" else a.grad_compress,
                        "final_loss": loss_val},
             "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (U0 forward, ConvTranspose1d 4096->2048 k32 s2)",
                          "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",

@@ -31,7 +31,7 @@ def shard_grads(rank):
     return {k: p[k].grad.detach().clone() for k in detgen.param_order()}
 
 
-def worker(rank, port, q):
+def worker(rank, port, q, compress=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
@@ -42,7 +42,7 @@ def worker(rank, port, q):
         g = shard_grads(rank)
         for k in detgen.param_order():
             arena.g(k).copy_(g[k])
-        red = BucketedAllReduce(arena)
+        red = BucketedAllReduce(arena, compress=compress)
         assert red.world == WORLD and red.buckets.covers_arena()
         for name in BACKWARD_ORDER:            # the order engine.backward() calls on_grads_ready
             red.launch(name)
@@ -63,11 +63,12 @@ def free_port():
     return port
 
 
-def test_bucketed_allreduce_equals_mean_of_replica_grads():
+@pytest.mark.parametrize("compress", [None, "bf16"])
+def test_bucketed_allreduce_equals_mean_of_replica_grads(compress):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, port, q)) for r in range(WORLD)]
+    procs = [ctx.Process(target=worker, args=(r, port, q, compress)) for r in range(WORLD)]
     for p in procs:
         p.start()
     avg = q.get(timeout=240)
@@ -77,7 +78,9 @@ def test_bucketed_allreduce_equals_mean_of_replica_grads():
     want = [shard_grads(r) for r in range(WORLD)]
     for k in detgen.param_order():
         w = (want[0][k] + want[1][k]).numpy() / WORLD
-        assert np.max(np.abs(avg[k] - w)) <= 1e-6 * max(np.max(np.abs(w)), 1e-12), k
+        # fp32 payload: exact to rounding; bf16 payload: each rank's gradient and the sum are rounded to bf16
+        tol = 1e-6 if compress is None else 1.2e-2
+        assert np.max(np.abs(avg[k] - w)) <= tol * max(np.max(np.abs(w)), 1e-12), k
 
 
 def test_buckets_follow_backward_order_and_tile_the_arena():

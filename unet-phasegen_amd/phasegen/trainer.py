@@ -50,9 +50,13 @@ class BucketedAllReduce:
     the layer's wgrad has been enqueued; ``wait_all()`` before the optimiser step.  The 1/world averaging is NOT
     applied here: Adam folds it into its single pass over the arena (grad_scale)."""
 
-    def __init__(self, arena, group=None, always=False):
+    def __init__(self, arena, group=None, always=False, compress=None):
+        if compress not in (None, "bf16"):
+            raise ValueError("compress: None (fp32 payload) or 'bf16'")
         self.buckets = GradBuckets(arena)
         self.group = group
+        self.compress = compress     # "bf16": the payload on the wire is bf16 (half the xGMI bytes; SURVEY.md K13, config 5);
+        self._wire = {}              #         the sum runs in bf16 inside the collective, the arena keeps fp32
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.always = always and dist.is_available() and dist.is_initialized()   # run the collective even at world 1 (tests)
         self.pending = []
@@ -60,23 +64,35 @@ class BucketedAllReduce:
 
     def launch(self, name):
         self.launched.append(name)
-        if self.world > 1 or self.always:
-            self.pending.append(dist.all_reduce(self.buckets.view(name), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if not (self.world > 1 or self.always):
+            return
+        g = self.buckets.view(name)
+        if self.compress is None:
+            self.pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+            return
+        wire = self._wire.get(name)
+        if wire is None:
+            wire = self._wire[name] = torch.empty(g.shape, dtype=torch.bfloat16, device=g.device)
+        wire.copy_(g)                                                          # fp32 -> bf16 (RNE) on the launch stream
+        self.pending.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True), wire, g))
 
     def wait_all(self):
-        for w in self.pending:
+        for w, wire, g in self.pending:
             w.wait()
+            if wire is not None:
+                g.copy_(wire)                                                  # bf16 sum -> fp32 arena
         self.pending.clear()
         done, self.launched = self.launched, []
         return done
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, mag_weight=0.2, always_reduce=False):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, mag_weight=0.2, always_reduce=False,
+                 grad_compress=None):
         self.model = model
         self.engine = model.engine
         self.optim = Adam(model.parameters(), lr=lr, betas=betas, eps=eps)
-        self.reducer = BucketedAllReduce(self.engine.arena, group, always=always_reduce)
+        self.reducer = BucketedAllReduce(self.engine.arena, group, always=always_reduce, compress=grad_compress)
         self.world = self.reducer.world
         self.mag_weight = mag_weight
         self.losses = torch.zeros(3, device=self.engine.device)

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--resume", default=None, help="checkpoint written by a previous run (ckpt_N + ckpt_N.optim)")
     ap.add_argument("--synthetic", type=int, default=0, help="train on N synthetic clips instead of --train (no dataset ships)")
     ap.add_argument("--frames", type=int, default=128, help="frames per synthetic clip")
+    ap.add_argument("--grad_compress", choices=["none", "bf16"], default="none", help="payload of the data-parallel gradient all-reduce")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
                     help="MFMA operand mode of the convolutions (pg_conv_set_precision): fp32 = the reference's arithmetic")
     a = ap.parse_args()
@@ -68,7 +69,7 @@ def main():
         loader = SpectrogramLoader(d, torch.zeros(a.synthetic, 1, device=d.device), a.batch_size, True, rank, world, seed=0)
     else:
         loader = get_fft_npy_loader([a.train], [0, 1], batch_size=a.batch_size, precon=True, rank=rank, world=world, seed=0)
-    trainer = Trainer(model, lr=a.lr)
+    trainer = Trainer(model, lr=a.lr, grad_compress=None if a.grad_compress == "none" else a.grad_compress)
     if a.resume:
         trainer.load_checkpoint(a.resume)
     val_loader = None
