@@ -675,6 +675,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
     const int kt = dma_kt(lane, wv);
+#if PG_ABL == 8   /* dev-only: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6) */
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int Lcol = TKIND ? p.U : p.Ly;              // columns (output positions) per sample
     const int Ktot = p.Q * KWP, Mrows = TKIND ? p.M * S : p.M;
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
@@ -807,6 +810,13 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         pos += se - sb;
         slot = 1;
     }
+#if PG_ABL == 8
+    if (tid == 0 && p.ws && blockIdx.x == gridDim.x / 2) {
+        unsigned long long* d = (unsigned long long*)p.ws;
+        d[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        d[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------------------------
