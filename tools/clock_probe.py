@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: in-kernel clock under load (s_memtime / s_memrealtime x 100 MHz, MI355X_MICROARCH.md 'DVFS give-back' item 6)
 of the U0-forward kernel in the three operand modes.  Needs a diagnostic build:
-    hipcc ... -DPG_ABL=8 -c conv_igemm.hip -o build/conv_clk.o ; link with the other objects into tools/abl/lib_clk.so"""
+    hipcc ... -DPG_ABL=8 -c conv_raw.hip -o build/conv_raw_clk.o ; link with the other objects into tools/abl/lib_clk.so"""
 import os, sys
 sys.path.insert(0, "unet-phasegen_amd"); sys.path.insert(0, ".")
 from phasegen import _lib

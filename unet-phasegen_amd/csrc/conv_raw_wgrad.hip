@@ -1,0 +1,188 @@
+// conv_raw_wgrad.hip -- raw-window variant of the G (wgrad) kernel.
+#include "conv_common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------------------------
+// Raw-window variant of the G (wgrad) kernel: dW[m][(q,j)] = sum_{k=(b,i)} P[b,m,i] * Q[b,q,s*i+j-p], tile 128 (m) x 256
+// ((q,j) columns = 256/k whole channels).  Per slab of 16 consecutive (b,i) the columns of one channel are k shifted
+// views of the SAME piece of Q's row: positions s*i0 - p + [0, 15 s + k).  That window is staged once per channel
+// (LDS image [sub][channel][WLP], sub 1 only filled when the slab runs over the end of sample b into b+1) and the
+// B fragment of column (q,j), slab element kl is read at  q*WLP + j + s*kl  (+ a wave-uniform shift for kl past the
+// sample boundary).  For k = 32 that is 6.4x fewer bytes than the im2col tile.
+// ----------------------------------------------------------------------------------------------------------------
+template <int KW, int S> struct GRaw {
+    static constexpr int WL = 15 * S + KW;                                   // window floats actually read
+    static constexpr int WLP = (KW == 32) ? 64 : (KW == 8 ? (S == 1 ? 24 : 40) : 36);   // padded; keeps reads conflict-free
+    static constexpr int NQT = RBN / KW;                                      // channels per tile
+    static constexpr int SUB = NQT * WLP;                                     // floats per sub-window set
+    static constexpr int NE = (SUB + NT - 1) / NT;                            // gather pieces per thread and sub-window
+    static constexpr int STG = RTILE_A + 2 * SUB;                             // floats per LDS stage
+    static_assert(WL <= WLP, "window does not fit its slot");
+};
+
+template <int KW, int S, int BF>
+__global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) {
+    using C = GRaw<KW, S>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * C::STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
+    const int kt = dma_kt(lane, wv);
+    const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    const float slopeA = act_slope(p.act_p), slopeB = act_slope(p.act_x);
+    const int pbs4 = (int)p.pt_bs * 4, xbs4 = (int)p.x_bs * 4;
+    const int g = xcd_remap(blockIdx.x, gridDim.x);
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);
+    int pos = split_lo(sp, g);
+    const int pos_end = split_lo(sp, g + 1);
+    int slot = 0;
+    while (pos < pos_end) {
+        const int tile = pos / p.nslab, sb = pos - tile * p.nslab;
+        const int se = min(p.nslab, sb + (pos_end - pos));
+        const int m0 = (tile / p.tilesN) * RBM, n0 = (tile % p.tilesN) * RBN;
+        const int qbase = n0 / KW;
+
+        int aoff[8];                                   // P[b][m][i]: byte offset of row m (this thread's k column added per slab)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int m = m0 + dma_row(lane, wv, e);
+            aoff[e] = m < p.M ? m * p.LP * 4 : FAR;
+        }
+        int choff[C::NE], vv[C::NE];                   // window element owned by this thread: channel byte offset, v - pad
+#pragma unroll
+        for (int e = 0; e < C::NE; ++e) {
+            const int idx = tid + NT * e, ql = idx / C::WLP, v = idx - ql * C::WLP;
+            choff[e] = (idx < C::SUB && qbase + ql < p.Q) ? (qbase + ql) * p.Lx * 4 : FAR;
+            vv[e] = v - p.p;
+        }
+        int bbase[4];                                  // fragment base of this lane's 4 columns
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int c = wn * 128 + jb * 32 + (lane & 31), qc = c / KW;
+            bbase[jb] = qc * C::WLP + (c - qc * KW) + S * 8 * (lane >> 5);
+        }
+        AccR acc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;
+
+        // wave-uniform (sample, frame) of the slab being GATHERED (one slab ahead of the one being multiplied)
+        int gb, gi;
+        { const int k0 = sb * BK; gb = k0 / p.LP; gi = k0 - gb * p.LP; }
+        int kc_cur = 16;                               // first slab element that belongs to the next sample (16 = none)
+
+#define GRAW_ISSUE(STAGE_PTR, K0)                                                                         \
+    {   float* const As = (STAGE_PTR) + wv * 64; float* const Bw = (STAGE_PTR) + RTILE_A + wv * 64;       \
+        const int k0 = (K0);                                                                              \
+        { int bb, ii; divmod24(k0 + kt, p.LP, p.inv_LP, bb, ii);                                          \
+          const int po = bb < p.B ? bb * pbs4 + ii * 4 : OOB;                                             \
+          _Pragma("unroll") for (int e = 0; e < 8; ++e) dma4(rp, As + e * 256, aoff[e] + po); }           \
+        const int kc = p.LP - gi;                      /* elements of this slab left in sample gb */      \
+        const int sb0 = gb < p.B ? gb * xbs4 : -NEVER, sb1 = (kc < 16 && gb + 1 < p.B) ? (gb + 1) * xbs4 : -NEVER; \
+        _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                               \
+            if (e * NT + wv * 64 < C::SUB) {                                                              \
+                const int ps = S * gi + vv[e];                                                            \
+                dma4(rx, Bw + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb0 >= 0) ? sb0 + choff[e] + ps * 4 : FAR); \
+            }                                                                                             \
+        }                                                                                                 \
+        if (kc < 16) {                                 /* slab runs into the next sample: second sub-window */ \
+            _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                           \
+                if (e * NT + wv * 64 < C::SUB) {                                                          \
+                    const int ps = vv[e];                                                                 \
+                    dma4(rx, Bw + C::SUB + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb1 >= 0) ? sb1 + choff[e] + ps * 4 : FAR); \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+        kc_next = kc < 16 ? kc : 16;                                                                      \
+        gi += BK; if (gi >= p.LP) { gi -= p.LP; ++gb; }                                                   \
+    }
+
+        int kc_next;
+        GRAW_ISSUE(lds, sb * BK)
+        kc_cur = kc_next;
+        __syncthreads();
+        for (int sl = sb; sl < se; ++sl) {
+            const int cur = (sl - sb) & 1;
+            GRAW_ISSUE(lds + (cur ^ 1) * C::STG, (sl + 1) * BK)
+            __builtin_amdgcn_sched_barrier(0);
+            {   // fragments + MFMA for slab sl
+                const float* As = lds + cur * C::STG;
+                const float* Bw = As + RTILE_A;
+                const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
+                const float* ap = As + (wm * 64 + r) * BK;
+                f32x4 a[2][2];
+                float b[4][8];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+                if (kc_cur >= 16) {
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) b[jb][i] = Bw[bbase[jb] + S * i];
+                } else {        // elements kl >= kc_cur live in the second sub-window, which starts at frame 0 of the next sample
+                    const int shift = C::SUB - S * kc_cur;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int d = (8 * h + i >= kc_cur) ? shift : 0;
+#pragma unroll
+                        for (int jb = 0; jb < 4; ++jb) b[jb][i] = Bw[bbase[jb] + S * i + d];
+                    }
+                }
+                if (slopeA != 1.0f) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) a[i][c][v] = act_apply(a[i][c][v], slopeA);
+                }
+                if (slopeB != 1.0f) {
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) b[jb][i] = act_apply(b[jb][i], slopeB);
+                }
+                if (BF) mfma_low_2x4<BF>(a, b, acc);
+                else {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk], acc.c[i][j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            kc_cur = kc_next;
+            __syncthreads();
+        }
+#undef GRAW_ISSUE
+        if (sb == 0 && se == p.nslab) epilogue_g<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+        else store_partial(p.ws, g, slot, acc, tid);
+        pos += se - sb;
+        slot = 1;
+    }
+}
+
+template <int KW, int S>
+hipError_t launch_g_raw(const IgemmParams& p, int grid, hipStream_t st, int prec) {
+    if (prec == 1) hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, 1>), dim3(grid), dim3(NT), 0, st, p);
+    else if (prec == 2) hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, 2>), dim3(grid), dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, 0>), dim3(grid), dim3(NT), 0, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t pgconv::launch_raw_g(const IgemmParams& p, int grid, hipStream_t st, int prec) {
+    if (p.k == 32) return launch_g_raw<32, 2>(p, grid, st, prec);
+    if (p.k == 8 && p.s == 1) return launch_g_raw<8, 1>(p, grid, st, prec);
+    if (p.k == 8) return launch_g_raw<8, 2>(p, grid, st, prec);
+    return launch_g_raw<4, 2>(p, grid, st, prec);
+}
