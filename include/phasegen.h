@@ -57,7 +57,7 @@ typedef struct pg_conv_args {
                                      /*   contents are garbage between calls; NULL = always one tile per WG */
 } pg_conv_args;
 int64_t pg_workspace_bytes_conv(void);
-int pg_conv_set_schedule(int mode);  /* test hook: bits 0-1: 0 auto, 1 one tile per workgroup, 2 force stream-K; bit 2: no raw-window kernels */
+int pg_conv_set_schedule(int mode);  /* test hook: bits 0-1: 0 auto, 1 one tile per workgroup, 2 force stream-K; bit 2: no raw-window kernels; bit 3: no tall (256 x 128) raw tile */
 /* Operand precision of the MFMA contraction (BASELINE config 5): 0 (default) = fp32 operands, v_mfma_f32_32x32x2_f32, the
  * 1e-4 parity path; 1 = operands rounded to bf16 (RNE, after the fused activation) at fragment load, v_mfma_f32_32x32x16_bf16,
  * fp32 accumulate -- tensors and master weights in HBM stay fp32; 2 = "bf16x3": every fp32 operand is split exactly into

@@ -22,11 +22,12 @@ ap.add_argument("--act", type=int, default=2)
 ap.add_argument("--precision", default="fp32")
 ap.add_argument("--schedule", type=int, default=0)
 ap.add_argument("--oversub", type=int, default=4)
+ap.add_argument("--frames", type=int, default=256)
 a = ap.parse_args()
 if a.lib:
     from phasegen import _lib
     _lib.LIB_PATH = os.path.abspath(a.lib)
-C, L, B = 1024, 256, a.batch
+C, L, B = 1024, a.frames, a.batch
 ops.set_conv_precision(a.precision)
 ops.set_conv_schedule(a.schedule)
 ops.set_conv_oversubscribe(a.oversub)

@@ -405,6 +405,7 @@ enum Kind { KIND_F, KIND_T, KIND_G };
 // Kernel launchers, one per translation unit.  `prec` = pg_conv_set_precision mode (0 fp32, 1 bf16, 2 bf16x3).
 namespace pgconv {
 hipError_t launch_im2col(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_im2col.hip
-hipError_t launch_raw_ft(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw.hip (F / T)
+hipError_t launch_raw_ft(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw.hip (F / T, tile 128 x 256)
+hipError_t launch_raw_ft_tall(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw_tall.hip (256 x 128)
 hipError_t launch_raw_g(const IgemmParams& p, int grid, hipStream_t st, int prec);              // conv_raw_wgrad.hip
 }  // namespace pgconv

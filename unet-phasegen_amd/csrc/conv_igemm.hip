@@ -13,7 +13,9 @@
 //
 // Two generations of kernels, selected per launch by the host (launch() below); sources:
 //   conv_common.h        problem descriptor, LDS-DMA helpers, MFMA operand modes, stream-K split, epilogues
-//   conv_raw.hip         RAW-WINDOW F/T kernels  } the fast path for every layer geometry of the U-Net except k = 5:
+//   conv_raw_impl.h      RAW-WINDOW F/T kernel template; conv_raw.hip instantiates the 128 x 256 tile (training), conv_raw_tall.hip the
+//                        256 x 128 tile (few columns: small-batch inference)
+//   conv_raw*.hip        RAW-WINDOW F/T kernels  } the fast path for every layer geometry of the U-Net except k = 5:
 //   conv_raw_wgrad.hip   RAW-WINDOW G kernel     } workgroup tile 128 (M) x 256 (N), 4 waves of 64 x 128 (128 accumulator
 //                        registers, 2 waves/SIMD).  The weight / P tile is gathered by LDS-DMA into a swizzled K-contiguous
 //                        image; the ACTIVATION operand is staged as raw row windows (every element once) and the im2col
@@ -38,35 +40,33 @@
 namespace {
 
 // ---- fixup: add the partial segments of every split tile in ascending workgroup order, then the epilogue ---------
-template <int KIND, int MB, int NB>
+// One workgroup per (tile, 32 x 32 block of the wave tile): with few tiles and many segments (small-batch inference: 8 tiles
+// split over 512 workgroups) one workgroup per tile would read 8 MB on its own; per block the reduction is MB*NB times wider.
+// WN = waves of the GEMM kernel along N (2: tile 64 MB x 64 NB; 1: the raw "tall" tile 128 MB x 32 NB).
+template <int KIND, int MB, int NB, int WN = 2>
 __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int G) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = WN == 2 ? wv >> 1 : wv, wn = WN == 2 ? wv & 1 : 0;
+    static_assert(MB * NB * 16 == ACC_REGS, "8 blocks per wave tile: the host launches 8 workgroups per tile");
+    const int tile = blockIdx.x / (MB * NB), blk = blockIdx.x - tile * (MB * NB), bi = blk / NB, bj = blk - bi * NB;
     const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, G);
     const int first = tile * p.nslab, last = first + p.nslab - 1;
     const int g0 = split_owner(sp, first), g1 = split_owner(sp, last);
     if (g0 == g1 && split_lo(sp, g0) <= first && split_lo(sp, g0 + 1) > last) return;   // computed whole by one workgroup
-    AccT<MB, NB> acc;
+    AccT<1, 1> acc;
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc.c[0][0][r] = 0.f;
     for (int g = g0; g <= g1; ++g) {
         const int slot = (split_lo(sp, g) / p.nslab == tile) ? 0 : 1;     // the range's first segment, or its last
         const float* src = p.ws + ((long)(g * 2 + slot) * ACC_REGS) * NT + tid;
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc.c[i][j][r] += src[((i * NB + j) * 16 + r) * NT];
+        for (int r = 0; r < 16; ++r) acc.c[0][0][r] += src[(blk * 16 + r) * NT];
     }
-    const int m0 = (tile / p.tilesN) * (64 * MB), n0 = (tile % p.tilesN) * (64 * NB);
-    if (KIND == 0) epilogue_f<0, MB, NB>(p, acc, m0, n0, lane, wm, wn);
-    else if (KIND == 1) epilogue_t<0, MB, NB>(p, acc, m0, n0, lane, wm, wn);
-    else epilogue_g<0, MB, NB>(p, acc, m0, n0, lane, wm, wn);
+    // the epilogues place block (0, 0) of wave (wm, wn) at m0 + wm * 32, n0 + wn * 32: shift the origin to block (bi, bj)
+    const int m0 = (tile / p.tilesN) * ((4 / WN) * 32 * MB) + wm * (MB - 1) * 32 + bi * 32;
+    const int n0 = (tile % p.tilesN) * (WN * 32 * NB) + wn * (NB - 1) * 32 + bj * 32;
+    if (KIND == 0) epilogue_f<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
+    else if (KIND == 1) epilogue_t<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
+    else epilogue_g<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -81,6 +81,7 @@ constexpr long WS_PER_WG = 2L * ACC_REGS * NT * 4;   // two partial tiles of 256
 // schedule knobs (process-wide; set through pg_conv_set_schedule / pg_conv_set_oversubscribe)
 int g_force_mode = 0;   // work split: 0 automatic, 1 one tile per workgroup, 2 force stream-K
 int g_force_raw = 0;    // 1 = never use the raw-window kernels (exercise the im2col kernels)
+int g_no_tall = 0;      // 1 = never use the tall 256 x 128 raw tile
 int g_oversub = 4;      // stream-K grid = up to g_oversub x resident workgroup slots
 
 int cu_count() { return pg_cu_count(); }
@@ -108,7 +109,7 @@ int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mo
 }
 
 // raw-window kernels: supported (k, s) pairs and the window-length bound
-bool raw_supported(Kind kind, const IgemmParams& p) {
+bool raw_supported(Kind kind, const IgemmParams& p, int tn = RBN) {
     if (g_force_raw == 1) return false;
     int kwp, sc, lcol;
     if (kind == KIND_F) {
@@ -122,32 +123,41 @@ bool raw_supported(Kind kind, const IgemmParams& p) {
         return p.LP >= 16 && ((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2));
     }
     const int tj = kwp < 16 ? kwp : 16;
-    const int nseg_max = (lcol - 1 + RBN - 1) / lcol + 1;
-    return sc * (RBN - 1) + tj + RG * (nseg_max - 1) + (kind == KIND_T ? tj : 0) <= (sc == 1 ? RS1 : RS2);
+    const int nseg_max = (lcol - 1 + tn - 1) / lcol + 1;
+    return sc * (tn - 1) + tj + RG * (nseg_max - 1) + (kind == KIND_T ? tj : 0) <= (sc == 1 ? RS1 : RS2);
 }
 
 int launch(Kind kind, IgemmParams& p, long rows, long cols, long Ktot, long ws_bytes, hipStream_t st) {
-    const bool raw = raw_supported(kind, p);
-    const int bm = raw ? RBM : BM, bn = raw ? RBN : BN;
+    bool raw = raw_supported(kind, p);
+    // F / T problems with few columns (inference at small batch: N = B * frames') take the tall 256 x 128 tile when it covers
+    // the columns with fewer computed ones (a 128 x 256 tile over 65 columns is 3/4 idle MFMA work per weight byte)
+    const bool tall = kind != KIND_G && g_force_raw == 0 && g_no_tall == 0 && cols <= 1024 && (cols + 127) / 128 * 128 < (cols + RBN - 1) / RBN * RBN &&
+                      raw_supported(kind, p, RBN / 2);
+    if (tall) raw = true;
+    const int bm = tall ? 2 * RBM : (raw ? RBM : BM), bn = tall ? RBN / 2 : (raw ? RBN : BN);
     p.tilesM = (int)((rows + bm - 1) / bm);
     p.tilesN = (int)((cols + bn - 1) / bn);
     p.nslab = (int)((Ktot + BK - 1) / BK);
     const long tiles = (long)p.tilesM * p.tilesN;
-    if (tiles <= 0 || tiles > 0x7fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");
+    if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");   // the fixup launches 8 workgroups per tile
     const int grid = pick_grid(tiles, p.nslab, p, ws_bytes, g_force_mode);
     hipError_t e;
     if (raw && kind == KIND_G) e = pgconv::launch_raw_g(p, grid, st, g_bf16);
+    else if (tall) e = pgconv::launch_raw_ft_tall(kind, p, grid, st, g_bf16);
     else if (raw) e = pgconv::launch_raw_ft(kind, p, grid, st, g_bf16);
     else e = pgconv::launch_im2col(kind, p, grid, st, g_bf16);
     if (e == hipSuccess && grid != tiles) {
-        if (raw) {
-            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid);
-            else if (kind == KIND_T) hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid);
-            else hipLaunchKernelGGL((conv_fixup_kernel<2, 2, 4>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid);
+        if (tall) {
+            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+            else hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+        } else if (raw) {
+            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+            else if (kind == KIND_T) hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+            else hipLaunchKernelGGL((conv_fixup_kernel<2, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
         } else switch (kind) {
-            case KIND_F: hipLaunchKernelGGL((conv_fixup_kernel<0, WMB, 2>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
-            case KIND_T: hipLaunchKernelGGL((conv_fixup_kernel<1, WMB, 2>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
-            case KIND_G: hipLaunchKernelGGL((conv_fixup_kernel<2, WMB, 2>), dim3((unsigned)tiles), dim3(NT), 0, st, p, grid); break;
+            case KIND_F: hipLaunchKernelGGL((conv_fixup_kernel<0, WMB, 2>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid); break;
+            case KIND_T: hipLaunchKernelGGL((conv_fixup_kernel<1, WMB, 2>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid); break;
+            case KIND_G: hipLaunchKernelGGL((conv_fixup_kernel<2, WMB, 2>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid); break;
         }
         e = hipGetLastError();
     }
@@ -288,9 +298,10 @@ extern "C" int64_t pg_workspace_bytes_conv(void) { return (int64_t)MAX_STREAMK_W
 // Test hook: 0 = automatic schedule, 1 = force one tile per workgroup, 2 = force stream-K (needs a workspace).
 extern "C" int pg_conv_set_schedule(int mode) {
     // bits 0-1: 0 automatic split, 1 one tile per workgroup, 2 force stream-K;  bit 2: disable the raw-window kernels
-    if (mode < 0 || mode > 7 || (mode & 3) == 3) return pg_fail(PG_ERR_SHAPE, "conv_set_schedule: bad mode");
+    if (mode < 0 || mode > 15 || (mode & 3) == 3) return pg_fail(PG_ERR_SHAPE, "conv_set_schedule: bad mode");
     g_force_mode = mode & 3;
     g_force_raw = (mode >> 2) & 1;
+    g_no_tall = (mode >> 3) & 1;
     return PG_OK;
 }
 

@@ -1,0 +1,270 @@
+// conv_raw_impl.h -- raw-window variants of the F and T kernels (conv fwd / convT dgrad; convT fwd / conv dgrad), as a
+// template over the workgroup tile shape; instantiated by conv_raw.hip (128 x 256) and conv_raw_tall.hip (256 x 128).
+#pragma once
+#include "conv_common.h"
+
+namespace {
+
+// ================================================================================================================
+// Raw-window variants of the F and T kernels: workgroup tile 128 (M) x 256 (N), wave tile 64 x 128.
+//
+// An im2col tile holds every activation element k/s times and needs one gather instruction per 64 elements.  Here the activation
+// operand is staged RAW: for each channel of a slab one contiguous window of the input row (every element once,
+// zero-filled outside [0, Lx)), and the im2col overlap is resolved when the MFMA fragments are read: column c of the
+// tile reads taps at window offset vcol(c) + tap (F) or vcol(c) - tap (T), vcol(c) = s'*c + 16*seg(c), where seg(c)
+// counts the sample boundaries between column 0 and c (a 16-float gap per boundary keeps windows of different samples
+// apart).  The tile is made wide on the activation side, where bytes are now cheap: per slab 8 KB of weights plus ~1-2 KB
+// of activations feed 128x256x16 MACs -- 60 % fewer global->LDS bytes per MFMA than the 256x128 im2col tiling.
+// Supported when the taps per channel in K order (F: k, T: k/s) are 4, 8, 16 or 32 and the windows fit RS floats;
+// everything else (k = 5, generic) stays on the im2col kernels.
+// ================================================================================================================
+// ds_read_b32-based B fragments: lane (column block jb, column r, half h) needs k = 8h .. 8h+7 of the slab, i.e.
+// (channel qi, tap tau) = divmod(8h + i, TJ); the element lives at  qi*RS + bbase[jb] +/- tau.
+struct RawFrags { f32x4 a[2][2]; float b[4][8]; };
+
+template <int TJ, bool DESC, int RS>
+__device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
+                                               const int (&bbase)[4], float slopeA, float slopeB, RawFrags& f) {
+    const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
+    const float* ap = As + (wm * 64 + r) * BK;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) f.a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+    // lane part of the index: TJ == 16 -> one channel, taps 8h + i;  TJ <= 8 -> channels (8/TJ)*h + i/TJ, taps i % TJ
+    const int lanepart = (TJ == 16) ? (DESC ? -8 * h : 8 * h) : (8 / TJ) * h * RS;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        const float* bp = Bw + bbase[jb] + lanepart;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int qoff = (TJ == 16) ? 0 : (i / TJ) * RS, tau = (TJ == 16) ? i : (i % TJ);
+            f.b[jb][i] = bp[qoff + (DESC ? -tau : tau)];
+        }
+    }
+    if (slopeA != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) f.a[i][c][v] = act_apply(f.a[i][c][v], slopeA);
+    }
+    if (slopeB != 1.0f) {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f.b[jb][i] = act_apply(f.b[jb][i], slopeB);
+    }
+}
+
+template <int BF>
+__device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
+    if (BF) { mfma_low_2x4<BF>(f.a, f.b, acc); return; }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk >> 2][kk & 3], f.b[j][kk], acc.c[i][j], 0, 0, 0);
+}
+
+template <int TJ, bool DESC, int RS, int BF>
+__device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
+                                             const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
+    RawFrags f;
+    raw_load_frags<TJ, DESC, RS>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
+    raw_mfma<BF>(f, acc);
+}
+
+// TKIND false: F (conv fwd / convT dgrad, taps ascend with stride s between columns)
+// TKIND true : T (convT fwd / conv dgrad in gather form, unit column stride, taps descend)
+// WN = waves along N: 2 -> workgroup tile 128 (M) x 256 (N), the training shape; 1 -> 256 x 128 ("tall"): the four waves are
+// stacked in M, for problems with few columns (batch-1 inference: N = frames' <= 128), where the wide tile would be mostly
+// empty and the pass is bound by MFMA time per weight byte.
+template <int KW, int S, bool TKIND, int BF, int WN>
+__global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
+    constexpr int TM = WN == 2 ? RBM : 2 * RBM, TN = WN == 2 ? RBN : RBN / 2;   // workgroup tile
+    constexpr int TA = TM * BK;                       // floats of the weight tile (8 / 16 KB)
+    constexpr int AE4 = TM / 16, AE16 = TM / 64;      // dword / 16-byte gather pieces per thread for the weight tile
+    constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
+    constexpr int TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ;
+    constexpr int SC = TKIND ? 1 : S;                 // window positions per column step
+    constexpr int RS = SC == 1 ? RS1 : RS2;           // floats reserved per channel window
+    constexpr int NPC = (RS + NT - 1) / NT;           // gather pieces per thread and window
+    constexpr int STG = TA + NQ * RS;                 // floats per LDS stage
+    constexpr int SPB = (4 * STG * 4 <= 64 * 1024) ? 2 : 1;   // slabs per barrier (two when both stages still fit 64 KB)
+    static_assert(KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "raw-window kernels need 4/8/16/32 taps per channel");
+    static_assert(!TKIND || KW % S == 0, "T raw kernel needs s | k");
+    __shared__ __attribute__((aligned(16))) float lds[2 * SPB * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = WN == 2 ? wv >> 1 : wv, wn = WN == 2 ? wv & 1 : 0;
+    const int kt = dma_kt(lane, wv);
+#if PG_ABL == 8   /* dev-only: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6) */
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int Lcol = TKIND ? p.U : p.Ly;              // columns (output positions) per sample
+    const int Ktot = p.Q * KWP, Mrows = TKIND ? p.M * S : p.M;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
+    const int wq = p.M * KW;                          // T: weight stride between input channels
+    const int g = xcd_remap(blockIdx.x, gridDim.x);
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);
+    int pos = split_lo(sp, g);
+    const int pos_end = split_lo(sp, g + 1);
+    int slot = 0;
+    while (pos < pos_end) {
+        const int tile = pos / p.nslab, sb = pos - tile * p.nslab;
+        const int se = min(p.nslab, sb + (pos_end - pos));
+        const int m0 = (tile / p.tilesN) * TM, n0 = (tile % p.tilesN) * TN;
+        const int b0 = n0 / Lcol, t0 = n0 - b0 * Lcol;            // sample / position of the tile's first column
+        const int nseg = (t0 + TN - 1) / Lcol + 1;
+        const int rlen = SC * (TN - 1) + TJ + RG * (nseg - 1);   // floats of a channel window that are ever read
+
+        // --- weight-tile gather constants (BYTE offsets) --------------------------------------------------------
+        int aoff[AE4], avoff[AE16];
+        if (TKIND) {
+#pragma unroll
+            for (int e = 0; e < AE4; ++e) {
+                const int mr = m0 + dma_row(lane, wv, e), o = mr / S, phi = mr - o * S;
+                aoff[e] = mr < Mrows ? (o * KW + phi) * 4 : FAR;              // W[q][o][S*jj + phi]
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < AE4; ++e) {
+                const int m = m0 + dma_row(lane, wv, e);
+                aoff[e] = (!p.a_vec && m < p.M) ? (m * Ktot + kt) * 4 : FAR;
+            }
+#pragma unroll
+            for (int e = 0; e < AE16; ++e) {
+                const int m = m0 + dma16_row(lane, wv, e);
+                avoff[e] = m < p.M ? (m * Ktot + dma16_kc(lane)) * 4 : FAR;
+            }
+        }
+        // --- window gather constants: thread owns window positions v = tid + 256 e --------------------------------
+        int posb[NPC], rowb[NPC];
+#pragma unroll
+        for (int e = 0; e < NPC; ++e) {
+            const int v = tid + 256 * e;
+            int k = 0;                                            // segment (sample) this window position belongs to
+            while (k + 1 < nseg && SC * ((k + 1) * Lcol - t0) + RG * (k + 1) <= v) ++k;
+            const int cs = k ? k * Lcol - t0 : 0;                 // first column of the segment
+            const int vl = v - (SC * cs + RG * k);                // position inside the segment's window
+            const int tf = k ? 0 : t0;                            // frame index of that first column
+            const int b = b0 + k;
+            // F: memory position = s*t - p + tau;  T: u - tau with u = u_off + t, stored ascending from u - (TJ-1)
+            posb[e] = b < p.B ? (TKIND ? p.u_off + tf - (TJ - 1) + vl : S * tf - p.p + vl) : -NEVER;
+            rowb[e] = b * (int)p.x_bs * 4;
+        }
+        // --- fragment bases: window offset of each of this lane's 4 columns ----------------------------------------
+        int bbase[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int c = wn * 128 + jb * 32 + (lane & 31);
+            bbase[jb] = SC * c + RG * ((t0 + c) / Lcol) + (TKIND ? TJ - 1 : 0);
+        }
+
+        AccR acc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;
+
+#define RAW_ISSUE(STAGE_PTR, K0)                                                                          \
+    {   float* const As = (STAGE_PTR) + wv * 64; float* const Bw = (STAGE_PTR) + TA + wv * 64;             \
+        const int k0 = (K0);                                                                              \
+        const bool kok = k0 < Ktot;                                                                       \
+        if (TKIND) {                                                                                      \
+            const int kk = k0 + kt, q = kk / KWP, jj = kk - q * KWP;                                      \
+            const int wo = kok ? (q * wq + S * jj) * 4 : OOB;                                             \
+            _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4(rw, As + e * 256, aoff[e] + wo);         \
+        } else if (p.a_vec) {                                                                             \
+            const int kv = (k0 + dma16_kc(lane) < Ktot) ? k0 * 4 : OOB;                                   \
+            _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16(rw, As + wv * 192 + e * 1024, avoff[e] + kv); \
+        } else {                                                                                          \
+            const int ka = (k0 + kt < Ktot) ? k0 * 4 : OOB;                                               \
+            _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4(rw, As + e * 256, aoff[e] + ka);         \
+        }                                                                                                 \
+        const int q0 = k0 / KWP, tau0 = k0 - q0 * KWP;    /* tau0 != 0 only when a channel spans two slabs */ \
+        _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                               \
+            const int qq = q0 + qi;                                                                       \
+            const int qo = (kok && qq < p.Q) ? qq * p.Lx : -NEVER;                                        \
+            _Pragma("unroll") for (int e = 0; e < NPC; ++e) {                                             \
+                if (e * 256 + wv * 64 < rlen) {                                                           \
+                    const int ps = posb[e] + (TKIND ? -tau0 : tau0);                                      \
+                    const bool ok = (unsigned)ps < (unsigned)p.Lx && qo >= 0;                             \
+                    dma4(rx, Bw + qi * RS + e * 256, ok ? rowb[e] + (qo + ps) * 4 : FAR);                 \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+
+        PG_STAMP_DECL
+        // Two 16-deep slabs per barrier when the stage pair fits (SPB = 2): each LDS stage holds two half-stages that are
+        // gathered together and multiplied one after the other, halving the barrier (and gather-burst) rate.  Fragments
+        // are still loaded 16 deep, so the register budget is unchanged.  The second half is skipped when it lies past
+        // this segment's end (it belongs to the next workgroup's range, or past K where the gathers returned zeros).
+        constexpr int SSTG = SPB * STG;
+        static_assert(2 * SSTG * 4 <= 64 * 1024, "LDS budget");
+#pragma unroll
+        for (int hf = 0; hf < SPB; ++hf) RAW_ISSUE(lds + hf * STG, (sb + hf) * BK)
+        __syncthreads();
+        for (int sl = sb; sl < se; sl += SPB) {
+            const int cur = ((sl - sb) / SPB) & 1;
+            PG_STAMP(0)
+#pragma unroll
+            for (int hf = 0; hf < SPB; ++hf) RAW_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, (sl + SPB + hf) * BK)
+            __builtin_amdgcn_sched_barrier(0);
+            PG_STAMP(1)
+            mma_slab_raw<TJ, TKIND, RS, BF>(lds + cur * SSTG, lds + cur * SSTG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+            if (SPB == 2 && sl + 1 < se)
+                mma_slab_raw<TJ, TKIND, RS, BF>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            PG_STAMP(2)
+            __syncthreads();
+            PG_STAMP(3)
+        }
+        PG_STAMP_FLUSH
+#undef RAW_ISSUE
+        if (sb == 0 && se == p.nslab) {
+            if (TKIND) epilogue_t<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+            else epilogue_f<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+        } else store_partial(p.ws, g, slot, acc, tid);
+        pos += se - sb;
+        slot = 1;
+    }
+#if PG_ABL == 8
+    if (tid == 0 && p.ws && blockIdx.x == gridDim.x / 2) {
+        unsigned long long* d = (unsigned long long*)p.ws;
+        d[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        d[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
+}
+
+template <int KW, int S, bool TK, int WN>
+hipError_t launch_raw(const IgemmParams& p, int grid, hipStream_t st, int prec) {
+    if (prec == 1) hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, 1, WN>), dim3(grid), dim3(NT), 0, st, p);
+    else if (prec == 2) hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, 2, WN>), dim3(grid), dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((conv_raw_kernel<KW, S, TK, 0, WN>), dim3(grid), dim3(NT), 0, st, p);
+    return hipGetLastError();
+}
+
+
+template <int WN>
+hipError_t launch_raw_ft_wn(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec) {
+    if (kind == KIND_F) {
+        if (p.k == 32) return launch_raw<32, 2, false, WN>(p, grid, st, prec);
+        if (p.k == 8 && p.s == 1) return launch_raw<8, 1, false, WN>(p, grid, st, prec);
+        if (p.k == 8) return launch_raw<8, 2, false, WN>(p, grid, st, prec);
+        return launch_raw<4, 2, false, WN>(p, grid, st, prec);
+    }
+    if (p.k == 32) return launch_raw<32, 2, true, WN>(p, grid, st, prec);
+    if (p.s == 1) return launch_raw<8, 1, true, WN>(p, grid, st, prec);
+    return launch_raw<8, 2, true, WN>(p, grid, st, prec);
+}
+
+}  // namespace

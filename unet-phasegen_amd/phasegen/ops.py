@@ -91,7 +91,7 @@ def conv_workspace(device):
 
 def set_conv_schedule(mode):
     """Test hook.  Bits 0-1: 0 automatic, 1 one tile per workgroup, 2 force the stream-K split; bit 2 (value 4):
-    disable the raw-window F/T kernels (use the im2col kernels)."""
+    disable the raw-window F/T kernels (use the im2col kernels); bit 3 (value 8): never pick the tall 256 x 128 raw tile."""
     _lib.check(_lib.load().pg_conv_set_schedule(mode), "conv_set_schedule")
 
 
