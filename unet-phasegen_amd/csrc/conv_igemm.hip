@@ -129,9 +129,12 @@ bool raw_supported(Kind kind, const IgemmParams& p, int tn = RBN) {
 
 int launch(Kind kind, IgemmParams& p, long rows, long cols, long Ktot, long ws_bytes, hipStream_t st) {
     bool raw = raw_supported(kind, p);
-    // F / T problems with few columns (inference at small batch: N = B * frames') take the tall 256 x 128 tile when it covers
-    // the columns with fewer computed ones (a 128 x 256 tile over 65 columns is 3/4 idle MFMA work per weight byte)
-    const bool tall = kind != KIND_G && g_force_raw == 0 && g_no_tall == 0 && cols <= 1024 && (cols + 127) / 128 * 128 < (cols + RBN - 1) / RBN * RBN &&
+    // F / T problems whose columns the tall 256 x 128 tile covers with at least 3 % fewer computed ones take it: small-batch
+    // inference above all (a 128 x 256 tile over 65 columns is 3/4 idle MFMA work per weight byte), and training shapes such as
+    // N = 16 x 65 (5 wide tiles = 1280 columns vs 9 tall = 1152: +15 % measured) or 64 x 30.  On ties the wide tile wins (it
+    // runs two slabs per barrier; measured 1-7 % faster at equal column counts).
+    const long cols_wide = (cols + RBN - 1) / RBN * RBN, cols_tall = (cols + RBN / 2 - 1) / (RBN / 2) * (RBN / 2);
+    const bool tall = kind != KIND_G && g_force_raw == 0 && g_no_tall == 0 && cols_tall * 100 <= cols_wide * 97 &&
                       raw_supported(kind, p, RBN / 2);
     if (tall) raw = true;
     const int bm = tall ? 2 * RBM : (raw ? RBM : BM), bn = tall ? RBN / 2 : (raw ? RBN : BN);
