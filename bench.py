@@ -7,7 +7,7 @@
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
-  roofline     dominant kernel (U0 forward = conv_raw_kernel<32,2,true,0>, the largest single GEMM: 4.43 TFLOP per launch at
+  roofline     dominant kernel (U0 forward = conv_raw_kernel<32,2,true,0,2>, the largest single GEMM: 4.43 TFLOP per launch at
                batch 64) -- algorithmic FLOPs per launch / its average launch duration measured here with HIP events
                on the launch stream, against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
   cpu_baseline the oracle (CPU restatement of the reference, oracle/unet_ref.py) doing the SAME training step on the
@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "unet-phasegen_amd"))
 sys.path.insert(0, ROOT)
 
-DOMINANT_KERNEL = "conv_raw_kernel<32, 2, true, 0>"   # the symbol rocprofv3 reports for the fp32 U0 forward launch
+DOMINANT_KERNEL = "conv_raw_kernel<32, 2, true, 0, 2>"   # the symbol rocprofv3 reports for the fp32 U0 forward launch
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 16 x the fp32 rate (v_mfma_f32_32x32x16_bf16: 32 cycles for 32 768 FLOP)
 
