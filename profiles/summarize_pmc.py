@@ -16,9 +16,15 @@ import os
 import sys
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same scratch directory: take the most recent run only."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def load(d):
     rows = []
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*counter_collection.csv")):
         rows += list(csv.DictReader(open(f)))
     return rows
 
@@ -26,7 +32,7 @@ def load(d):
 def main():
     tag, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
     here = os.path.dirname(os.path.abspath(__file__))
-    src = glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0]
+    src = newest(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0]
     open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w").write(open(src).read())
     summ = collections.defaultdict(dict)
     for d in pmc_dirs:
