@@ -35,6 +35,15 @@ def test_trainer_step_through_rccl_single_rank_group():
         assert torch.equal(l1, l2)
         assert torch.equal(m1.engine.arena.flat, m2.engine.arena.flat)
         assert torch.equal(m1.engine.arena.grad, m2.engine.arena.grad)
+        # bf16 payload: the same step with every bucket rounded to bf16, reduced by RCCL as bf16 and widened back
+        m3 = UNetModel(C, 2 * C).load_numpy(pn)
+        t3 = Trainer(m3, always_reduce=True, grad_compress="bf16")
+        l3 = t3.step(batch).clone()
+        m4 = UNetModel(C, 2 * C).load_numpy(pn)
+        l4 = Trainer(m4).step(batch).clone()
+        assert torch.equal(l3, l4)                                      # the forward pass does not see the payload format
+        g3, g4 = m3.engine.arena.grad, m4.engine.arena.grad
+        assert torch.equal(g3, g4.to(torch.bfloat16).float())          # exactly the bf16 rounding of the fp32 gradient
         dist.barrier()
     finally:
         dist.destroy_process_group()
