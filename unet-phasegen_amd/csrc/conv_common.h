@@ -102,6 +102,13 @@ __device__ __forceinline__ void dma16(rsrc_t r, float* lds_wave_uniform, int byt
 __device__ __forceinline__ void dma4(rsrc_t r, float* lds_wave_uniform, int byte_off) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 4, PG_ADDR(byte_off), 0, 0, 0);
 }
+// per-lane offset fixed for the tile + a wave-uniform (SGPR) offset that advances with the slab: no VALU per gather
+__device__ __forceinline__ void dma4s(rsrc_t r, float* lds_wave_uniform, int lane_off, int uniform_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 4, lane_off, uniform_off, 0, 0);
+}
+__device__ __forceinline__ void dma16s(rsrc_t r, float* lds_wave_uniform, int lane_off, int uniform_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 16, lane_off, uniform_off, 0, 0);
+}
 
 // bf16 operand mode (pg_conv_set_precision(1)): the same fragments -- lane (row, h) already holds k = 8h .. 8h+7 of the
 // slab, which is exactly the operand layout of v_mfma_f32_32x32x16_bf16 -- are rounded to bf16 (RNE, v_cvt_pk_bf16_f32)

@@ -157,6 +157,30 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             posb[e] = b < p.B ? (TKIND ? p.u_off + tf - (TJ - 1) + vl : S * tf - p.p + vl) : -NEVER;
             rowb[e] = b * (int)p.x_bs * 4;
         }
+        // --- fast gather path (fp32, wide tile): whole slabs inside K need no per-gather index math.  Every gather offset splits
+        // into a per-lane part that is fixed for the tile and a wave-uniform part that advances with the slab and rides in the
+        // SGPR offset operand of the buffer load.
+        //   T weights: K index k0 + kt (k0 multiple of 16, KWP | 16) = channel k0/KWP + kt/KWP, tap kt%KWP: the kt terms are per lane
+        //   F weights: row offset per lane, k0 * 4 uniform
+        //   windows:   position validity is per lane; channel (and, for 32-tap channels, the 0 / 16 tap offset tau0 of the slab)
+        //              is uniform.  With tau0 in {0, 16} the validity of a position can differ: two per-lane offsets (NT0 sets).
+        constexpr bool FAST = BF == 0 && WN == 2;
+        constexpr int NT0 = (!TKIND && KWP == 32) ? 2 : 1;
+        int aoffk[(FAST && TKIND) ? AE4 : 1], voffb[FAST ? NT0 : 1][FAST ? NPC : 1];
+        if (FAST) {
+            if (TKIND) {
+                const int lk = ((kt / KWP) * wq + S * (kt % KWP)) * 4;
+#pragma unroll
+                for (int e = 0; e < AE4; ++e) aoffk[e] = aoff[e] == FAR ? FAR : aoff[e] + lk;
+            }
+#pragma unroll
+            for (int h = 0; h < NT0; ++h)
+#pragma unroll
+                for (int e = 0; e < NPC; ++e) {
+                    const int ps = posb[e] + 16 * h;              // F: + tau0 (T kernels always have tau0 = 0).  tau0 stays in the
+                    voffb[h][e] = (unsigned)ps < (unsigned)p.Lx ? rowb[e] + ps * 4 : FAR;   // per-lane part: that one is range-checked
+                }
+        }
         // --- fragment bases: window offset of each of this lane's 4 columns ----------------------------------------
         int bbase[4];
 #pragma unroll
@@ -177,6 +201,25 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     {   float* const As = (STAGE_PTR) + wv * 64; float* const Bw = (STAGE_PTR) + TA + wv * 64;             \
         const int k0 = (K0);                                                                              \
         const bool kok = k0 < Ktot;                                                                       \
+        if (FAST && k0 + BK <= Ktot) {                                                                    \
+            if (TKIND) {                                                                                  \
+                const int sa = (k0 / KWP) * wq * 4;                                                       \
+                _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4s(rw, As + e * 256, aoffk[TKIND ? e : 0], sa); \
+            } else if (p.a_vec) {                                                                         \
+                _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], k0 * 4); \
+            } else {                                                                                      \
+                _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4s(rw, As + e * 256, aoff[e], k0 * 4); \
+            }                                                                                             \
+            const int fq0 = k0 / KWP, ft0 = k0 - fq0 * KWP;              /* ft0 = 16 only for the odd slabs of 32-tap channels */ \
+            _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                           \
+                const int sq = (fq0 + qi) * p.Lx * 4;                                                     \
+                _Pragma("unroll") for (int e = 0; e < NPC; ++e)                                           \
+                    if (e * 256 + wv * 64 < rlen) {                                                       \
+                        if (NT0 == 2 && ft0) dma4s(rx, Bw + qi * RS + e * 256, voffb[NT0 - 1][e], sq);    \
+                        else dma4s(rx, Bw + qi * RS + e * 256, voffb[0][e], sq);                          \
+                    }                                                                                     \
+            }                                                                                             \
+        } else {                                                                                          \
         if (TKIND) {                                                                                      \
             const int kk = k0 + kt, q = kk / KWP, jj = kk - q * KWP;                                      \
             const int wo = kok ? (q * wq + S * jj) * 4 : OOB;                                             \
@@ -199,6 +242,7 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
                     dma4(rx, Bw + qi * RS + e * 256, ok ? rowb[e] + (qo + ps) * 4 : FAR);                 \
                 }                                                                                         \
             }                                                                                             \
+        }                                                                                                 \
         }                                                                                                 \
     }
 
