@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         //   F weights: row offset per lane, k0 * 4 uniform
         //   windows:   position validity is per lane; channel (and, for 32-tap channels, the 0 / 16 tap offset tau0 of the slab)
         //              is uniform.  With tau0 in {0, 16} the validity of a position can differ: two per-lane offsets (NT0 sets).
-        constexpr bool FAST = BF == 0 && WN == 2;
+        constexpr bool FAST = !(BF == 2 && TKIND);       // (the bf16x3 T kernels are at the 256-VGPR limit: the 8 extra offsets would spill)
         constexpr int NT0 = (!TKIND && KWP == 32) ? 2 : 1;
         int aoffk[(FAST && TKIND) ? AE4 : 1], voffb[FAST ? NT0 : 1][FAST ? NPC : 1];
         if (FAST) {
