@@ -55,6 +55,18 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
             choff[e] = (idx < C::SUB && qbase + ql < p.Q) ? (qbase + ql) * p.Lx * 4 : FAR;
             vv[e] = v - p.p;
         }
+        // Slabs that lie inside one sample (all but one in LP/16) read the P tile as two 16-byte pieces per thread: 16 consecutive
+        // frames of a row are contiguous (16-byte LDS-DMA only needs dword alignment, tools/probe/ldsdma16.hip), the (sample, frame)
+        // of the slab is wave-uniform and rides in the SGPR offset.  Enabled where registers allow.
+        constexpr bool FASTP = BF != 2 && (KW == 32 || (KW == 8 && S == 1));
+        int pv[FASTP ? 2 : 1];
+        if (FASTP) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int m = m0 + dma16_row(lane, wv, e);
+                pv[e] = m < p.M ? (m * p.LP + dma16_kc(lane)) * 4 : FAR;
+            }
+        }
         int bbase[4];                                  // fragment base of this lane's 4 columns
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
@@ -77,10 +89,14 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
 #define GRAW_ISSUE(STAGE_PTR, K0)                                                                         \
     {   float* const As = (STAGE_PTR) + wv * 64; float* const Bw = (STAGE_PTR) + RTILE_A + wv * 64;       \
         const int k0 = (K0);                                                                              \
-        { int bb, ii; divmod24(k0 + kt, p.LP, p.inv_LP, bb, ii);                                          \
+        const int kc = p.LP - gi;                      /* elements of this slab left in sample gb */      \
+        if (FASTP && kc >= 16 && gb < p.B) {                                                              \
+            const int sa = gb * pbs4 + gi * 4;                                                            \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) dma16s(rp, As + wv * 192 + e * 1024, pv[FASTP ? e : 0], sa); \
+        } else {                                                                                          \
+          int bb, ii; divmod24(k0 + kt, p.LP, p.inv_LP, bb, ii);                                          \
           const int po = bb < p.B ? bb * pbs4 + ii * 4 : OOB;                                             \
           _Pragma("unroll") for (int e = 0; e < 8; ++e) dma4(rp, As + e * 256, aoff[e] + po); }           \
-        const int kc = p.LP - gi;                      /* elements of this slab left in sample gb */      \
         const int sb0 = gb < p.B ? gb * xbs4 : -NEVER, sb1 = (kc < 16 && gb + 1 < p.B) ? (gb + 1) * xbs4 : -NEVER; \
         _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                               \
             if (e * NT + wv * 64 < C::SUB) {                                                              \
