@@ -164,11 +164,20 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         //   F weights: row offset per lane, k0 * 4 uniform
         //   windows:   position validity is per lane; channel (and, for 32-tap channels, the 0 / 16 tap offset tau0 of the slab)
         //              is uniform.  With tau0 in {0, 16} the validity of a position can differ: two per-lane offsets (NT0 sets).
-        constexpr bool FAST = !(BF == 2 && TKIND);       // (the bf16x3 T kernels are at the 256-VGPR limit: the 8 extra offsets would spill)
+        constexpr bool FAST = !(BF == 2 && TKIND);       // (the bf16x3 T kernels are at the 256-VGPR limit: the extra offsets would spill)
         constexpr int NT0 = (!TKIND && KWP == 32) ? 2 : 1;
-        int aoffk[(FAST && TKIND) ? AE4 : 1], voffb[FAST ? NT0 : 1][FAST ? NPC : 1];
+        //   T weights at stride 1: the taps of a channel are contiguous in memory AND in K, so the tile loads as 16-byte pieces
+        constexpr bool T16 = TKIND && S == 1;
+        int aoffk[(FAST && TKIND && !T16) ? AE4 : 1], avoffk[(FAST && T16) ? AE16 : 1], voffb[FAST ? NT0 : 1][FAST ? NPC : 1];
         if (FAST) {
-            if (TKIND) {
+            if (T16) {
+                const int kc = dma16_kc(lane);
+#pragma unroll
+                for (int e = 0; e < AE16; ++e) {
+                    const int o = m0 + dma16_row(lane, wv, e);
+                    avoffk[e] = o < Mrows ? ((kc / KWP) * wq + o * KW + (kc % KWP)) * 4 : FAR;
+                }
+            } else if (TKIND) {
                 const int lk = ((kt / KWP) * wq + S * (kt % KWP)) * 4;
 #pragma unroll
                 for (int e = 0; e < AE4; ++e) aoffk[e] = aoff[e] == FAR ? FAR : aoff[e] + lk;
@@ -202,9 +211,12 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         const int k0 = (K0);                                                                              \
         const bool kok = k0 < Ktot;                                                                       \
         if (FAST && k0 + BK <= Ktot) {                                                                    \
-            if (TKIND) {                                                                                  \
+            if (T16) {                                                                                    \
                 const int sa = (k0 / KWP) * wq * 4;                                                       \
-                _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4s(rw, As + e * 256, aoffk[TKIND ? e : 0], sa); \
+                _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoffk[T16 ? e : 0], sa); \
+            } else if (TKIND) {                                                                           \
+                const int sa = (k0 / KWP) * wq * 4;                                                       \
+                _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4s(rw, As + e * 256, aoffk[(TKIND && !T16) ? e : 0], sa); \
             } else if (p.a_vec) {                                                                         \
                 _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], k0 * 4); \
             } else {                                                                                      \
