@@ -141,12 +141,16 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
 #pragma unroll
                         for (int i = 0; i < 8; ++i) b[jb][i] = Bw[bbase[jb] + S * i];
                 } else {        // elements kl >= kc_cur live in the second sub-window, which starts at frame 0 of the next sample
+                    // (volatile reads: otherwise hipcc sinks the loads of both paths into one tail with per-element selected
+                    // addresses, which cost the common path 60 VALU and left its 32 reads unpaired)
+                    typedef const volatile __attribute__((address_space(3))) float* lds_vptr;
+                    const lds_vptr Bv = (lds_vptr)Bw;
                     const int shift = C::SUB - S * kc_cur;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int d = (8 * h + i >= kc_cur) ? shift : 0;
 #pragma unroll
-                        for (int jb = 0; jb < 4; ++jb) b[jb][i] = Bw[bbase[jb] + S * i + d];
+                        for (int jb = 0; jb < 4; ++jb) b[jb][i] = Bv[bbase[jb] + S * i + d];
                     }
                 }
                 if (slopeA != 1.0f) {
