@@ -35,11 +35,18 @@ __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, con
     const int lanepart = (TJ == 16) ? (DESC ? -8 * h : 8 * h) : (8 / TJ) * h * RS;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
-        const float* bp = Bw + bbase[jb] + lanepart;
+        // descending taps are read as base - (TD - 1) + (TD - 1 - tau): every constant offset stays non-negative and small, so
+        // the reads pair into ds_read2_b32 with immediate offsets off ONE address register per column block (negative offsets made
+        // hipcc materialise an address per pair)
+        constexpr int TD = TJ < 8 ? TJ : 8;
+        typedef const __attribute__((address_space(3))) float* lds_ptr;
+        lds_ptr bp = (lds_ptr)(Bw + bbase[jb] + lanepart - (DESC ? TD - 1 : 0));
+        if (DESC) asm volatile("" : "+v"(bp));   // opaque base (T form: measured +1 %; F form: -1 %, left to the compiler): otherwise
+                                                 // the stage / tile constants are folded into one address register per read pair
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int qoff = (TJ == 16) ? 0 : (i / TJ) * RS, tau = (TJ == 16) ? i : (i % TJ);
-            f.b[jb][i] = bp[qoff + (DESC ? -tau : tau)];
+            f.b[jb][i] = bp[qoff + (DESC ? TD - 1 - tau : tau)];
         }
     }
     if (slopeA != 1.0f) {
