@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         //   F weights: row offset per lane, k0 * 4 uniform
         //   windows:   position validity is per lane; channel (and, for 32-tap channels, the 0 / 16 tap offset tau0 of the slab)
         //              is uniform.  With tau0 in {0, 16} the validity of a position can differ: two per-lane offsets (NT0 sets).
-        constexpr bool FAST = !(BF == 2 && TKIND);       // (the bf16x3 T kernels are at the 256-VGPR limit: the extra offsets would spill)
+        constexpr bool FAST = !(BF == 2 && TKIND && !(KW == 32 && WN == 2));   // (the other bf16x3 T kernels are at the 256-VGPR limit: the extra offsets spill)
         constexpr int NT0 = (!TKIND && KWP == 32) ? 2 : 1;
         //   T weights at stride 1: the taps of a channel are contiguous in memory AND in K, so the tile loads as 16-byte pieces
         constexpr bool T16 = TKIND && S == 1;
@@ -242,7 +242,15 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         if (TKIND) {                                                                                      \
             const int kk = k0 + kt, q = kk / KWP, jj = kk - q * KWP;                                      \
             const int wo = kok ? (q * wq + S * jj) * 4 : OOB;                                             \
-            _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4(rw, As + e * 256, aoff[e] + wo);         \
+            if (FAST && !T16) {      /* the general offsets are the fast ones minus their per-lane K part (keeps aoff[] dead) */ \
+                const int lk_ = ((kt / KWP) * wq + S * (kt % KWP)) * 4;                                   \
+                _Pragma("unroll") for (int e = 0; e < AE4; ++e) {                                         \
+                    const int ak = aoffk[(FAST && TKIND && !T16) ? e : 0];                                \
+                    dma4(rw, As + e * 256, (ak == FAR ? FAR : ak - lk_) + wo);                            \
+                }                                                                                         \
+            } else {                                                                                      \
+                _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4(rw, As + e * 256, aoff[e] + wo);     \
+            }                                                                                             \
         } else if (p.a_vec) {                                                                             \
             const int kv = (k0 + dma16_kc(lane) < Ktot) ? k0 * 4 : OOB;                                   \
             _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16(rw, As + wv * 192 + e * 1024, avoff[e] + kv); \
