@@ -39,12 +39,13 @@ GEOMS = [
 ]
 
 
-@pytest.fixture(params=[1, 2, 5, 6], ids=["raw/tile-per-wg", "raw/stream-k", "im2col/tile-per-wg", "im2col/stream-k"])
+@pytest.fixture(params=[1, 2, 5, 6, 10], ids=["raw/tile-per-wg", "raw/stream-k", "im2col/tile-per-wg", "im2col/stream-k", "raw-wide-only/stream-k"])
 def schedule(request):
     """Run the conv tests under both work decompositions (one whole tile per workgroup; the persistent stream-K split
     with partial tiles through the workspace + fixup kernel, which the library otherwise only picks for tile counts
     that quantise badly over the CUs) and with the raw-window F/T kernels enabled or disabled (bit 2), so the im2col
-    kernels they normally replace stay covered."""
+    kernels they normally replace stay covered; bit 3 keeps the small problems of this file on the wide 128 x 256 raw tile
+    (they otherwise take the tall 256 x 128 one), so both tile shapes see every geometry."""
     from phasegen import ops
     ops.set_conv_schedule(request.param)
     yield request.param
