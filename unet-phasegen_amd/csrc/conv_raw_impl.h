@@ -101,7 +101,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     constexpr int RS = SC == 1 ? RS1 : RS2;           // floats reserved per channel window
     constexpr int NPC = (RS + NT - 1) / NT;           // gather pieces per thread and window
     constexpr int STG = TA + NQ * RS;                 // floats per LDS stage
-    constexpr int SPB = (4 * STG * 4 <= 64 * 1024) ? 2 : 1;   // slabs per barrier (two when both stages still fit 64 KB)
+    // slabs per barrier: two when both stages still fit 64 KB -- except the k = 32 T kernel (U0 forward), which measures 2 %
+    // faster with one (146 vs 143 TFLOP/s); the F form and the k = 8 kernels gain 1-5 % from two
+    constexpr int SPB = (4 * STG * 4 <= 64 * 1024 && !(TKIND && KW == 32)) ? 2 : 1;
     static_assert(KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "raw-window kernels need 4/8/16/32 taps per channel");
     static_assert(!TKIND || KW % S == 0, "T raw kernel needs s | k");
     __shared__ __attribute__((aligned(16))) float lds[2 * SPB * STG];
