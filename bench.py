@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
 import argparse
 import json
 import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
 import sys
 import time
 

@@ -13,6 +13,7 @@ The path has no exchange step: under torch.distributed.run every rank processes 
 Prints one JSON line (rank 0): frames/s and clips/s over all ranks, per-stage milliseconds (HIP events).
 """
 import argparse, json, os, sys, time
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "unet-phasegen_amd")); sys.path.insert(0, ROOT)
 import torch

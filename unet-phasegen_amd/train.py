@@ -16,6 +16,7 @@ written instead.
 import argparse
 import json
 import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
 import sys
 import time
 
