@@ -116,14 +116,17 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
         gi += BK; if (gi >= p.LP) { gi -= p.LP; ++gb; }                                                   \
     }
 
+        PG_STAMP_DECL
         int kc_next;
         GRAW_ISSUE(lds, sb * BK)
         kc_cur = kc_next;
         __syncthreads();
         for (int sl = sb; sl < se; ++sl) {
             const int cur = (sl - sb) & 1;
+            PG_STAMP(0)
             GRAW_ISSUE(lds + (cur ^ 1) * C::STG, (sl + 1) * BK)
             __builtin_amdgcn_sched_barrier(0);
+            PG_STAMP(1)
             {   // fragments + MFMA for slab sl
                 const float* As = lds + cur * C::STG;
                 const float* Bw = As + RTILE_A;
@@ -179,9 +182,12 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            PG_STAMP(2)
             kc_cur = kc_next;
             __syncthreads();
+            PG_STAMP(3)
         }
+        PG_STAMP_FLUSH
 #undef GRAW_ISSUE
         if (sb == 0 && se == p.nslab) epilogue_g<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
         else store_partial(p.ws, g, slot, acc, tid);
