@@ -226,19 +226,25 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             } else if (TKIND) {                                                                           \
                 const int sa = (k0 / KWP) * wq * 4;                                                       \
                 _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4s(rw, As + e * 256, aoffk[(TKIND && !T16) ? e : 0], sa); \
-            } else if (p.a_vec) {                                                                         \
+            } else {     /* F: 16-byte pieces always (they only need dword alignment); no branch on a_vec here */ \
                 _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], k0 * 4); \
-            } else {                                                                                      \
-                _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4s(rw, As + e * 256, aoff[e], k0 * 4); \
             }                                                                                             \
             const int fq0 = k0 / KWP, ft0 = k0 - fq0 * KWP;              /* ft0 = 16 only for the odd slabs of 32-tap channels */ \
-            _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                           \
-                const int sq = (fq0 + qi) * p.Lx * 4;                                                     \
-                _Pragma("unroll") for (int e = 0; e < NPC; ++e)                                           \
-                    if (e * 256 + wv * 64 < rlen) {                                                       \
-                        if (NT0 == 2 && ft0) dma4s(rx, Bw + qi * RS + e * 256, voffb[NT0 - 1][e], sq);    \
-                        else dma4s(rx, Bw + qi * RS + e * 256, voffb[0][e], sq);                          \
-                    }                                                                                     \
+            /* pieces that every tile needs (the shortest window is SC*(TN-1)+TJ floats) issue without the per-wave check; */ \
+            /* one branch per slab picks the offset set (ft0), not one per piece */                       \
+            constexpr int RMIN = SC * (TN - 1) + TJ;                                                      \
+            if (NT0 == 2 && ft0) {                                                                        \
+                _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                       \
+                    const int sq = (fq0 + qi) * p.Lx * 4;                                                 \
+                    _Pragma("unroll") for (int e = 0; e < NPC; ++e)                                       \
+                        if ((e + 1) * 256 <= RMIN || e * 256 + wv * 64 < rlen) dma4s(rx, Bw + qi * RS + e * 256, voffb[NT0 - 1][e], sq); \
+                }                                                                                         \
+            } else {                                                                                      \
+                _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                       \
+                    const int sq = (fq0 + qi) * p.Lx * 4;                                                 \
+                    _Pragma("unroll") for (int e = 0; e < NPC; ++e)                                       \
+                        if ((e + 1) * 256 <= RMIN || e * 256 + wv * 64 < rlen) dma4s(rx, Bw + qi * RS + e * 256, voffb[0][e], sq); \
+                }                                                                                         \
             }                                                                                             \
         } else {                                                                                          \
         if (TKIND) {                                                                                      \
