@@ -99,14 +99,14 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
           _Pragma("unroll") for (int e = 0; e < 8; ++e) dma4(rp, As + e * 256, aoff[e] + po); }           \
         const int sb0 = gb < p.B ? gb * xbs4 : -NEVER, sb1 = (kc < 16 && gb + 1 < p.B) ? (gb + 1) * xbs4 : -NEVER; \
         _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                               \
-            if (e * NT + wv * 64 < C::SUB) {                                                              \
+            if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) {                                                              \
                 const int ps = S * gi + vv[e];                                                            \
                 dma4(rx, Bw + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb0 >= 0) ? sb0 + choff[e] + ps * 4 : FAR); \
             }                                                                                             \
         }                                                                                                 \
         if (kc < 16) {                                 /* slab runs into the next sample: second sub-window */ \
             _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                           \
-                if (e * NT + wv * 64 < C::SUB) {                                                          \
+                if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) {                                                          \
                     const int ps = vv[e];                                                                 \
                     dma4(rx, Bw + C::SUB + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb1 >= 0) ? sb1 + choff[e] + ps * 4 : FAR); \
                 }                                                                                         \
