@@ -59,8 +59,10 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
         // frames of a row are contiguous (16-byte LDS-DMA only needs dword alignment, tools/probe/ldsdma16.hip), the (sample, frame)
         // of the slab is wave-uniform and rides in the SGPR offset.  Enabled where registers allow.
         constexpr bool FASTP = BF != 2 && (KW == 32 || (KW == 8 && S == 1));
-        int pv[FASTP ? 2 : 1];
+        int pv[FASTP ? 2 : 1], woff[FASTP ? C::NE : 1];   // (+ window element: channel offset + position inside the window)
         if (FASTP) {
+#pragma unroll
+            for (int e = 0; e < C::NE; ++e) woff[e] = choff[e] == FAR ? FAR : choff[e] + (vv[e] + p.p) * 4;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int m = m0 + dma16_row(lane, wv, e);
@@ -97,9 +99,15 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
           int bb, ii; divmod24(k0 + kt, p.LP, p.inv_LP, bb, ii);                                          \
           const int po = bb < p.B ? bb * pbs4 + ii * 4 : OOB;                                             \
           _Pragma("unroll") for (int e = 0; e < 8; ++e) dma4(rp, As + e * 256, aoff[e] + po); }           \
+        const int w0 = S * gi - p.p;                   /* memory position of window element 0 */          \
+        if (FASTP && kc >= 16 && gb < p.B && w0 >= 0 && w0 + C::WLP <= p.Lx) {   /* window inside the row: no per-lane checks */ \
+            const int sw_ = gb * xbs4 + w0 * 4;                                                           \
+            _Pragma("unroll") for (int e = 0; e < C::NE; ++e)                                             \
+                if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) dma4s(rx, Bw + e * NT, woff[FASTP ? e : 0], sw_); \
+        } else {                                                                                          \
         const int sb0 = gb < p.B ? gb * xbs4 : -NEVER, sb1 = (kc < 16 && gb + 1 < p.B) ? (gb + 1) * xbs4 : -NEVER; \
         _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                               \
-            if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) {                                                              \
+            if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) {                                    \
                 const int ps = S * gi + vv[e];                                                            \
                 dma4(rx, Bw + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb0 >= 0) ? sb0 + choff[e] + ps * 4 : FAR); \
             }                                                                                             \
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
                     dma4(rx, Bw + C::SUB + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb1 >= 0) ? sb1 + choff[e] + ps * 4 : FAR); \
                 }                                                                                         \
             }                                                                                             \
+        }                                                                                                 \
         }                                                                                                 \
         kc_next = kc < 16 ? kc : 16;                                                                      \
         gi += BK; if (gi >= p.LP) { gi -= p.LP; ++gb; }                                                   \
