@@ -6,17 +6,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
-  roofline     dominant kernel (U0 forward = conv_raw_kernel<32,2,true,0,2>, the largest single GEMM: 4.43 TFLOP per launch at
-               batch 64) -- algorithmic FLOPs per launch / its average launch duration measured here with HIP events
-               on the launch stream, against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
-  cpu_baseline the oracle (CPU restatement of the reference, oracle/unet_ref.py) doing the SAME training step on the
-               host cores on a bounded sample (batch 16 of the same C=1024, L=256 model); rank 0, N = 1 only.
-  kernels      per-layer conv timings (ms, TFLOP/s) for DESIGN.md's table.
-  other_precisions  (N = 1, default fp32 run only) the same step re-timed for 5 steps in the two optional MFMA operand modes
-               (pg_conv_set_precision): "bf16x3" = fp32 operands split into hi + lo bf16, 3 bf16 MFMA products (~5e-6 from
-               exact, passes the golden parity suite) and "bf16" = operands rounded to bf16 (BASELINE configs[4]).  Reported
-               beside the headline, never as `value`.
+Rank 0 prints ONE JSON line (contract in the task statement).  How the numbers are taken:
+
+  value / ms_per_step   K steps timed CLEAN (no events inside the region), barrier + synchronize on both sides, max over ranks.
+  kernels               a SECOND pass (3 steps) with one HIP-event pair per conv launch on the launch stream; every label carries
+                        the kernel symbol the library launches for it (pg_conv_describe: the name rocprofv3 reports).
+  roofline              the kernel with the LARGEST total time per step in that pass (not the fastest one): its algorithmic FLOPs
+                        per step / its time per step against the MFMA peak of the operand precision (fp32: 157.3 TFLOP/s,
+                        MI355X_MICROARCH.md), plus `step_frac` (all 23 conv passes' FLOPs / the clean step time), `worst_kernel`
+                        (lowest fraction among kernels holding >= 0.3 % of the step) and `by_kernel`.  Every entry can be
+                        recomputed from profiles/rNN_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this same command):
+                        calls and total time per kernel symbol there = launches_per_step x steps and ms_per_step here.
+  cpu_baseline          the oracle (CPU restatement of the reference, oracle/unet_ref.py) doing the SAME training step on the
+                        host cores on a bounded sample (batch 16 of the same C=1024, L=256 model); rank 0, N = 1 only.
+  other_precisions      (N = 1, fp32 run only) the same step re-timed in the two optional MFMA operand modes ("bf16x3", "bf16").
+                        Reported beside the headline, never as `value`.
+  dp                    (N > 1) self-diagnosis of the data-parallel path: ranks that really took part in an all-reduce, a checksum
+                        of the parameter arena compared across ranks (a diverged replica FAILS the bench), each bucket's
+                        all-reduce timed alone, the compute-only step and the fraction of communication hidden under backward.
+
+Other configurations (never the default, never what the driver records):
+    --config fwd   BASELINE configs[1]: forward only, batch 32 x 1024 x 256, fp32
+    --config e2e   BASELINE configs[4]: stereo clips -> STFT 2048/512 + polar -> U-Net forward (bf16 MFMA operands) -> ISTFT
 """
 import argparse
 import json
@@ -29,9 +40,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "unet-phasegen_amd"))
 sys.path.insert(0, ROOT)
 
-DOMINANT_KERNEL = "conv_raw_kernel<32, 2, true, 0, 2>"   # the symbol rocprofv3 reports for the fp32 U0 forward launch
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 16 x the fp32 rate (v_mfma_f32_32x32x16_bf16: 32 cycles for 32 768 FLOP)
+DTYPES = {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate",
+          "bf16x3": "f32 operands split hi+lo into 3 bf16 MFMA products / f32 accumulate"}
 
 
 def conv_flops(C, L, B):
@@ -56,18 +68,18 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN_pmc_summary.json:
-    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate --pmc passes of this same command), else None."""
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN_pmc_summary.json: FETCH_SIZE x2
+    per the gfx950 correction + WRITE_SIZE, separate --pmc passes of this same command), else None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
-        return None
+        return None, None
     d = json.load(open(files[-1]))
     for k, v in d.items():
-        if kernel_substr in k and "hbm_read_bytes_corrected" in v:
-            return v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0)
-    return None
+        if kernel + "(" in k and "hbm_read_bytes_corrected" in v:
+            return v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0), os.path.basename(files[-1])
+    return None, None
 
 
 def cpu_baseline(C, L, max_threads=None):
@@ -101,8 +113,310 @@ def cpu_baseline(C, L, max_threads=None):
     dt = time.perf_counter() - t0
     return {"value": B * L / dt, "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"1 full training step (fwd+loss+bwd+Adam) of the same C={C}, L={L} model at batch {B} "
-                      f"({B * L} frames) by oracle/unet_ref.py (stock fp32 torch CPU ops, oneDNN off: see DESIGN.md), "
-                      f"{dt:.1f} s wall"}
+                      f"({B * L} frames) by oracle/unet_ref.py (stock fp32 torch CPU ops; oneDNN is OFF because its "
+                      f"multi-threaded ConvTranspose1d is wrong at this size, DESIGN.md §2 -- so this baseline is the ATen native "
+                      f"path and understates what a correct oneDNN build would do), {dt:.1f} s wall"}
+
+
+def synthetic_batch(torch, B, C, L, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    re = torch.randn(B, C, L, device="cuda", generator=gen)
+    im = torch.randn(B, C, L, device="cuda", generator=gen)
+    return torch.stack([torch.log1p(torch.sqrt(re * re + im * im)),
+                        (torch.rand(B, C, L, device="cuda", generator=gen) * 2 - 1) * torch.pi], dim=1).contiguous()
+
+
+def kernel_pass(torch, ops, step_fn, steps, fl, peak, step_ms):
+    """Second pass: per-launch HIP events, grouped by the kernel symbol each label launches."""
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    ops.set_timer(None)
+    ks, by = {}, {}
+    for label, (n, ms) in sorted(timer.summary().items()):
+        plan = timer.plans.get(label, "?")
+        kern = plan.split("|")[0]
+        f = fl[label.split(".")[0]]
+        ks[label] = {"launches": n, "ms": round(ms, 4), "tflops": round(f / ms / 1e9, 2), "kernel": kern,
+                     "plan": plan.split("|", 1)[1] if "|" in plan else ""}
+        e = by.setdefault(kern, {"launches_per_step": 0, "ms_per_step": 0.0, "flops_per_step": 0.0, "layers": []})
+        e["launches_per_step"] += 1
+        e["ms_per_step"] += ms
+        e["flops_per_step"] += f
+        e["layers"].append(label)
+    for e in by.values():
+        e["tflops"] = round(e["flops_per_step"] / e["ms_per_step"] / 1e9, 2)
+        e["frac"] = round(e["tflops"] / peak, 4)
+        e["share_of_step"] = round(e["ms_per_step"] / step_ms, 4)
+        e["ms_per_step"] = round(e["ms_per_step"], 4)
+    return ks, by
+
+
+def roofline_of(by, peak, step_tflops, precision, headline_shape):
+    dom = max(by, key=lambda k: by[k]["ms_per_step"])
+    big = {k: v for k, v in by.items() if v["share_of_step"] >= 0.003}
+    worst = min(big, key=lambda k: big[k]["frac"])
+    d = by[dom]
+    traffic, src = pmc_traffic(dom) if headline_shape and precision == "fp32" else (None, None)
+    return {"bound": "mfma", "kernel": dom + " (" + ", ".join(d["layers"]) + ")",
+            "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE)", "traffic_source": src,
+            "launches_per_step": d["launches_per_step"], "ms_per_step_in_kernel": d["ms_per_step"], "share_of_step": d["share_of_step"],
+            "flops_per_launch": d["flops_per_step"] / d["launches_per_step"],
+            "ms_per_launch": d["ms_per_step"] / d["launches_per_step"],
+            "step_tflops": round(step_tflops, 2), "step_frac": round(step_tflops / peak, 4),
+            "worst_kernel": {"kernel": worst + " (" + ", ".join(by[worst]["layers"]) + ")", "tflops": by[worst]["tflops"],
+                             "frac": by[worst]["frac"], "ms_per_step": by[worst]["ms_per_step"]},
+            "by_kernel": by}
+
+
+def dp_diagnostics(torch, dist, trainer, batch, world, step_ms):
+    """N > 1 only.  Fails (SystemExit) when the replicas' parameters differ after the timed steps."""
+    from phasegen.unet import BACKWARD_ORDER
+    eng = trainer.engine
+    flat = eng.arena.flat
+    # (1) ranks that really take part in a collective, and identical parameters everywhere
+    one = torch.ones(1, device="cuda")
+    dist.all_reduce(one)
+    chk = torch.zeros(2, device="cuda", dtype=torch.float64)
+    for s0 in range(0, flat.numel(), 1 << 26):
+        c = flat[s0:s0 + (1 << 26)].double()
+        chk[0] += c.sum()
+        chk[1] += (c * c).sum()
+    got = [torch.empty_like(chk) for _ in range(world)]
+    dist.all_gather(got, chk)
+    same = all(torch.equal(got[0], t) for t in got)
+    out = {"rccl_ranks": int(one.item()), "backend": dist.get_backend(), "replicas_identical": bool(same),
+           "param_checksum": [float(v) for v in got[0].cpu()]}
+    if not same:
+        print(json.dumps({"error": "data-parallel replicas diverged", "checksums": [[float(v) for v in t.cpu()] for t in got]}), flush=True)
+        raise SystemExit(3)
+    # (2) every bucket's all-reduce alone on an otherwise idle chip (events on the launch stream, which waits for RCCL's)
+    red = trainer.reducer
+    alone = {}
+    for rep in range(2):
+        for name in BACKWARD_ORDER:
+            g = red.buckets.view(name)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=red.group)
+            b.record()
+            torch.cuda.synchronize()
+            alone[name] = a.elapsed_time(b)
+    total = sum(alone.values())
+    payload = sum(red.buckets.view(n).numel() for n in BACKWARD_ORDER) * 4
+    # (3) the same step without communication
+    red.enabled = False
+    for _ in range(1):
+        trainer.step(batch)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    red.enabled = True
+    nocomm = float(t.item())
+    exposed = max(0.0, step_ms - nocomm)
+    out.update({"allreduce_alone_ms": {k: round(v, 3) for k, v in alone.items()}, "allreduce_alone_total_ms": round(total, 3),
+                "allreduce_payload_bytes": payload,
+                "allreduce_busbw_GBps": round(payload * 2 * (world - 1) / world / (total * 1e-3) / 1e9, 1),
+                "step_ms_compute_only": round(nocomm, 3), "comm_exposed_ms": round(exposed, 3),
+                "comm_hidden_frac": round(max(0.0, min(1.0, 1.0 - exposed / total)), 4) if total > 0 else None})
+    return out
+
+
+def run_train(a, torch, dist, world, rank, local):
+    from phasegen import ops
+    from phasegen.model import UNetModel
+    from phasegen.trainer import Trainer
+    C, L, B = a.channels, a.frames, a.batch
+    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    torch.manual_seed(0)
+    model = UNetModel(C, 2 * C, gpu_ids=[local], precision=a.precision)
+    trainer = Trainer(model, lr=1e-3, grad_compress=None if a.grad_compress == "none" else a.grad_compress)
+    batch = synthetic_batch(torch, B, C, L, 1 + rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = trainer.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = [float(v) for v in losses.cpu()]
+    step_ms = dt / a.steps * 1e3
+    dp = dp_diagnostics(torch, dist, trainer, batch, world, step_ms) if world > 1 else None
+
+    fl = conv_flops(C, L, B)
+    step_flops = 3 * sum(fl.values()) - fl["D0"]
+    ks, by = kernel_pass(torch, ops, lambda: trainer.step(batch), 3, fl, peak, step_ms)
+    if rank != 0:
+        return
+    frames = world * B * L * a.steps
+    out = {
+        "metric": "spectrogram-frames/sec (train fwd+bwd)", "value": frames / dt, "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPES[a.precision], "data": "synthetic",
+        "config": {"workload": f"train.py full step (fwd + cos/sin/mag loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}), "
+                               f"UNetModel({C}, {2 * C}), per-GPU batch {B} x {C} bins x {L} frames (BASELINE configs[2]{'/[3]' if world > 1 else ''})",
+                   "global_batch": world * B, "frames": L, "channels": C, "parallelism": f"dp{world}",
+                   "grad_allreduce_payload": "fp32" if a.grad_compress == "none" else a.grad_compress,
+                   "final_loss": loss_val},
+        "roofline": roofline_of(by, peak, step_flops / (dt / a.steps) / 1e12, a.precision, (C, L, B) == (1024, 256, 64)),
+        "kernels": ks,
+    }
+    if dp is not None:
+        out["dp"] = dp
+    if world == 1 and a.precision == "fp32" and not a.no_other_precisions:
+        other = {}
+        for mode in ("bf16x3", "bf16"):
+            model.engine.precision = ops.precision_code(mode)
+            for _ in range(2):
+                trainer.step(batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                trainer.step(batch)
+            torch.cuda.synchronize()
+            d1 = (time.perf_counter() - t1) / 5
+            other[mode] = {"ms_per_step": d1 * 1e3, "frames_per_s": B * L / d1, "step_tflops": round(step_flops / d1 / 1e12, 2)}
+        model.engine.precision = ops.precision_code("fp32")
+        out["other_precisions"] = other
+    if world == 1 and not a.no_cpu_baseline and a.precision == "fp32":
+        del trainer, model, batch
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(C, L, a.cpu_threads)
+    print(json.dumps(out), flush=True)
+
+
+def run_fwd(a, torch, dist, world, rank, local):
+    """BASELINE configs[1]: forward only (train-mode BatchNorm, as the reference always runs it), batch 32 x 1024 x 256."""
+    from phasegen import ops
+    from phasegen.model import UNetModel
+    C, L, B = a.channels, a.frames, (a.batch if a.batch != 64 else 32)
+    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    torch.manual_seed(0)
+    model = UNetModel(C, 2 * C, gpu_ids=[local], precision=a.precision)
+    x = synthetic_batch(torch, B, C, L, 1 + rank)[:, 0].contiguous()
+    fwd = lambda: model.engine.forward(x, update_stats=True)
+    for _ in range(a.warmup):
+        fwd()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        fwd()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fl = conv_flops(C, L, B)
+    step_ms = dt / a.steps * 1e3
+    ks, by = kernel_pass(torch, ops, fwd, 3, fl, peak, step_ms)
+    if rank != 0:
+        return
+    enc = sum(fl[n] for n in ("D0", "D1", "D2", "D3")) / sum(ks[n + ".fwd"]["ms"] for n in ("D0", "D1", "D2", "D3")) / 1e9
+    print(json.dumps({
+        "metric": "spectrogram-frames/sec (forward only)", "value": world * B * L * a.steps / dt, "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True,
+        "scaling": "weak (replicas only)", "vs_baseline": None, "dtype": DTYPES[a.precision], "data": "synthetic",
+        "config": {"workload": f"UNetModel({C}, {2 * C}).forward, train-mode BatchNorm, batch {B} x {C} bins x {L} frames (BASELINE configs[1])",
+                   "global_batch": world * B, "frames": L, "channels": C},
+        "roofline": roofline_of(by, peak, sum(fl.values()) / (dt / a.steps) / 1e12, a.precision, False),
+        "encoder_convs": {"tflops": round(enc, 2), "frac": round(enc / peak, 4),
+                          "note": "D0-D3 forward together: BASELINE.json's '>= 50 % of the MFMA-fp32 roofline on the encoder convs'"},
+        "kernels": ks}), flush=True)
+
+
+def run_e2e(a, torch, dist, world, rank, local):
+    """BASELINE configs[4]: stereo clips (2 mono signals each) of 130 560 samples -> STFT 2048/512 fused with log1p|z| / angle ->
+    U-Net forward (bf16 MFMA operands by default) -> ISTFT of (exp(m) - 1) e^{j phi}.  No exchange step: ranks are replicas."""
+    from phasegen import audio, ops
+    from phasegen.model import UNetModel
+    n_fft, hop, n = 2048, 512, 255 * 512
+    prec = a.precision if a.precision_given else "bf16"
+    peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    C, clips = n_fft // 2, (a.batch if a.batch != 64 else 32)
+    nsig, frames = 2 * clips, 1 + n // hop
+    torch.manual_seed(0)
+    model = UNetModel(C, 2 * C, gpu_ids=[local], precision=prec)
+    g = torch.Generator(device="cuda").manual_seed(1 + rank)
+    wav = torch.randn(nsig, n, device="cuda", generator=g) * 0.1
+    polar = torch.empty(nsig, 2, C, frames, device="cuda")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    stage = [0.0, 0.0, 0.0]
+
+    def step(record=False):
+        if record:
+            ev[0].record()
+        ops.stft(wav, n_fft, hop, polar=True, out=polar)
+        if record:
+            ev[1].record()
+        pred = model.engine.forward(polar[:, 0], update_stats=False)
+        if record:
+            ev[2].record()
+        outs = [audio.synthesize(polar[i:i + 64, 0], pred[i:i + 64, :C], hop) for i in range(0, nsig, 64)]
+        if record:
+            ev[3].record()
+            torch.cuda.synchronize()
+            for i in range(3):
+                stage[i] += ev[i].elapsed_time(ev[i + 1])
+        return outs
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out[0].shape == (min(64, nsig), hop * (frames - 1)) and bool(torch.isfinite(out[0]).all())
+    for _ in range(3):
+        step(True)
+    fl = conv_flops(C, frames, nsig)
+    step_ms = dt / a.steps * 1e3
+    ks, by = kernel_pass(torch, ops, lambda: model.engine.forward(polar[:, 0], update_stats=False), 3, fl, peak, step_ms)
+    if rank != 0:
+        return
+    print(json.dumps({
+        "metric": "spectrogram-frames/sec end to end (STFT + U-Net forward + ISTFT)", "value": world * nsig * frames * a.steps / dt,
+        "unit": "frames/s", "clips_per_s": world * clips * a.steps / dt, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak (replicas only)", "vs_baseline": None,
+        "dtype": DTYPES[prec], "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4]: {clips} stereo clips x {n} samples per rank, 2048-FFT / 512-hop, "
+                               f"STFT+polar -> UNetModel({C}, {2 * C}).forward -> ISTFT", "signals_per_rank": nsig, "frames": frames},
+        "stage_ms": {"stft+polar": stage[0] / 3, "unet_forward": stage[1] / 3, "istft": stage[2] / 3},
+        "roofline": roofline_of(by, peak, sum(fl.values()) / (stage[1] / 3 * 1e-3) / 1e12, prec, False),
+        "kernels": ks}), flush=True)
 
 
 def main():
@@ -110,18 +424,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=["train", "fwd", "e2e"], default="train",
+                    help="train = the headline (BASELINE configs[2]/[3]); fwd = configs[1]; e2e = configs[4]")
     ap.add_argument("--channels", type=int, default=1024, help="C (bins); 1024 = the reference's hard-coded model")
     ap.add_argument("--frames", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
-                    help="MFMA operand precision: fp32 = the parity path and the headline; bf16 = BASELINE configs[4]'s arithmetic "
-                         "(bf16 operands, fp32 accumulate, fp32 tensors and master weights) -- reported separately")
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (fwd / e2e default: 32 samples / 32 stereo clips)")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default=None,
+                    help="MFMA operand precision: fp32 = the parity path and the headline (default; e2e defaults to bf16 = BASELINE "
+                         "configs[4]'s arithmetic: bf16 operands, fp32 accumulate, fp32 tensors and master weights)")
     ap.add_argument("--grad-compress", choices=["none", "bf16"], default="none",
                     help="N > 1: payload of the gradient all-reduce (bf16 halves the xGMI bytes; default fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None)
     a = ap.parse_args()
+    a.precision_given = a.precision is not None
+    if a.precision is None:
+        a.precision = "fp32"
 
     import torch
     import torch.distributed as dist
@@ -139,94 +458,7 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-
-    from phasegen import ops
-    from phasegen.model import UNetModel
-    from phasegen.trainer import Trainer
-
-    C, L, B = a.channels, a.frames, a.batch
-    ops.set_conv_precision(a.precision)
-    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-    torch.manual_seed(0)
-    model = UNetModel(C, 2 * C, gpu_ids=[local])
-    trainer = Trainer(model, lr=1e-3, grad_compress=None if a.grad_compress == "none" else a.grad_compress)
-    gen = torch.Generator(device="cuda").manual_seed(1 + rank)
-    re = torch.randn(B, C, L, device="cuda", generator=gen)
-    im = torch.randn(B, C, L, device="cuda", generator=gen)
-    batch = torch.stack([torch.log1p(torch.sqrt(re * re + im * im)),
-                         (torch.rand(B, C, L, device="cuda", generator=gen) * 2 - 1) * torch.pi], dim=1).contiguous()
-    del re, im
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        trainer.step(batch)
-    timer = ops.KernelTimer()
-    ops.set_timer(timer)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses = trainer.step(batch)
-    sync()
-    dt = time.perf_counter() - t0
-    ops.set_timer(None)
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss_val = [float(v) for v in losses.cpu()]
-
-    if rank == 0:
-        fl = conv_flops(C, L, B)
-        ks = {}
-        for label, (n, ms) in sorted(timer.summary().items()):
-            ks[label] = {"launches": n, "ms": round(ms, 4), "tflops": round(fl[label.split(".")[0]] / ms / 1e9, 2)}
-        dom = ks["U0.fwd"]
-        frames = world * B * L * a.steps
-        out = {
-            "metric": "spectrogram-frames/sec (train fwd+bwd)", "value": frames / dt, "unit": "frames/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate",
-                      "bf16x3": "f32 operands split hi+lo into 3 bf16 MFMA products / f32 accumulate"}[a.precision], "data": "synthetic",
-            "config": {"workload": f"train.py full step (fwd + cos/sin/mag loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}), "
-                                   f"UNetModel({C}, {2 * C}), per-GPU batch {B} x {C} bins x {L} frames (BASELINE configs[2]{'/[3]' if world > 1 else ''})",
-                       "global_batch": world * B, "frames": L, "channels": C, "parallelism": f"dp{world}",
-                       "grad_allreduce_payload": "fp32" if a.grad_compress == "none" else a.grad_compress,
-                       "final_loss": loss_val},
-            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (U0 forward, ConvTranspose1d 4096->2048 k32 s2)",
-                         "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / peak,
-                         "traffic": pmc_traffic(DOMINANT_KERNEL) if (C, L, B, a.precision) == (1024, 256, 64, "fp32") else None,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
-                         "flops_per_launch": fl["U0"], "ms_per_launch": dom["ms"],
-                         "step_tflops": round((3 * sum(fl.values()) - fl["D0"]) / (dt / a.steps) / 1e12, 2)},
-            "kernels": ks,
-        }
-        if world == 1 and a.precision == "fp32" and not a.no_other_precisions:
-            other = {}
-            for mode in ("bf16x3", "bf16"):
-                ops.set_conv_precision(mode)
-                for _ in range(2):
-                    trainer.step(batch)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(5):
-                    trainer.step(batch)
-                torch.cuda.synchronize()
-                d1 = (time.perf_counter() - t1) / 5
-                other[mode] = {"ms_per_step": d1 * 1e3, "frames_per_s": B * L / d1,
-                               "step_tflops": round((3 * sum(fl.values()) - fl["D0"]) / d1 / 1e12, 2)}
-            ops.set_conv_precision("fp32")
-            out["other_precisions"] = other
-        if world == 1 and not a.no_cpu_baseline and a.precision == "fp32":
-            del trainer, model, batch
-            torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(C, L, a.cpu_threads)
-        print(json.dumps(out), flush=True)
+    {"train": run_train, "fwd": run_fwd, "e2e": run_e2e}[a.config](a, torch, dist, world, rank, local)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

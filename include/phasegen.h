@@ -10,7 +10,9 @@
  *   - activations are (B, channels, frames), frames fastest; a tensor is given as {ptr, batch_stride}
  *     (elements) so a channel slice of a wider buffer (the U-Net's concat halves) is passed without copy.
  *   - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing and keeps
- *     no mutable global state besides a thread-local last-error string.
+ *     no mutable global state besides a thread-local last-error string: every knob (MFMA operand precision,
+ *     work-split schedule, FFT schedule) is a field of the call's argument struct, so calls on different
+ *     streams / threads are independent.  A workspace belongs to ONE stream at a time.
  *   - every call is asynchronous on the hipStream_t passed as `void* stream`; no internal syncs.
  *   - return 0 on success, <0 = PG_ERR_* (bad argument), >0 = hipError_t from the launch.
  */
@@ -22,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PG_VERSION 100 /* 0.1.0 */
+#define PG_VERSION 200 /* 0.2.0: precision / schedule / transform mode travel in the argument structs; no process-wide setters */
 
 enum { PG_OK = 0, PG_ERR_NULL = -1, PG_ERR_SHAPE = -2, PG_ERR_ALIGN = -3, PG_ERR_UNSUPPORTED = -4,
        PG_ERR_WORKSPACE = -5 };
@@ -38,14 +40,16 @@ typedef struct pg_conv_args {
     int32_t B, Cin, Cout, Lin, Lout, k, stride, pad;
     const float* x;  int64_t x_bs;   /* forward input; read by *_fwd and *_wgrad                           */
     int32_t x_act;                   /* PG_ACT_* applied to x as it is read (the in-place (Leaky)ReLU that  */
-    int32_t _pad0;                   /*   precedes the conv in model.py:91,96,103 is never materialised)    */
+                                     /*   precedes the conv in model.py:91,96,103 is never materialised)    */
+    int32_t precision;               /* PG_PREC_*: operand precision of the MFMA contraction (below)        */
     const float* w;                  /* weights (layout above); read by *_fwd and *_dgrad                  */
     float* y;        int64_t y_bs;   /* forward output; written by *_fwd                                   */
     const float* dy; int64_t dy_bs;  /* grad wrt y; read by *_dgrad and *_wgrad                            */
     float* dx;       int64_t dx_bs;  /* grad wrt the tensor x was read from; written by *_dgrad            */
     const float* dx_add; int64_t dx_add_bs; /* optional (NULL): added to the dgrad result before masking (skip grad) */
     const float* dx_ref; int64_t dx_ref_bs; /* optional (NULL): dx *= act'(dx_ref) with act = dx_mask              */
-    int32_t dx_mask; int32_t _pad1;
+    int32_t dx_mask;
+    int32_t schedule;                /* 0 = automatic; otherwise PG_SCHED_* bits (tests and measurements)   */
     float* dw;                       /* grad wrt w, same layout as w; OVERWRITTEN by *_wgrad (beta = 0:     */
                                      /*   optim.zero_grad(), train.py:41, is folded into the write)         */
     int32_t y_act; int32_t y2_act;   /* *_fwd only: activation applied to the result as it is STORED (producers can */
@@ -57,15 +61,17 @@ typedef struct pg_conv_args {
                                      /*   contents are garbage between calls; NULL = always one tile per WG */
 } pg_conv_args;
 int64_t pg_workspace_bytes_conv(void);
-int pg_conv_set_schedule(int mode);  /* test hook: bits 0-1: 0 auto, 1 one tile per workgroup, 2 force stream-K; bit 2: no raw-window kernels; bit 3: no tall (256 x 128) raw tile */
-/* Operand precision of the MFMA contraction (BASELINE config 5): 0 (default) = fp32 operands, v_mfma_f32_32x32x2_f32, the
- * 1e-4 parity path; 1 = operands rounded to bf16 (RNE, after the fused activation) at fragment load, v_mfma_f32_32x32x16_bf16,
- * fp32 accumulate -- tensors and master weights in HBM stay fp32; 2 = "bf16x3": every fp32 operand is split exactly into
- * hi + lo bf16 parts and each product is taken as hi*hi' + hi*lo' + lo*hi' on the bf16 pipe (three MFMAs at 1/16 of the fp32
- * cost; ~5e-6 from exact against fp32 MFMA's ~1e-6: inside the 1e-4 parity bound, not fp32).  Applies to every conv kernel.
- * Process-wide.  Environment: PHASEGEN_CONV_PRECISION=fp32|bf16|bf16x3 sets it when the Python host loads the library. */
-int pg_conv_set_precision(int32_t mode);
-int pg_conv_set_oversubscribe(int factor); /* stream-K grid = factor x resident slots (1..8); > 1 when other kernels (RCCL) share the chip */
+/* pg_conv_args.precision (BASELINE config 5): PG_PREC_FP32 (0, default) = fp32 operands, v_mfma_f32_32x32x2_f32, the 1e-4
+ * parity path; PG_PREC_BF16 = operands rounded to bf16 (RNE, after the fused activation) at fragment load,
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulate -- tensors and master weights in HBM stay fp32; PG_PREC_BF16X3 = every fp32
+ * operand is split exactly into hi + lo bf16 parts and each product is taken as hi*hi' + hi*lo' + lo*hi' on the bf16 pipe
+ * (three MFMAs at 1/16 of the fp32 cost; ~5e-6 from exact against fp32 MFMA's ~1e-6: inside the 1e-4 parity bound, not fp32). */
+enum { PG_PREC_FP32 = 0, PG_PREC_BF16 = 1, PG_PREC_BF16X3 = 2 };
+/* pg_conv_args.schedule: bits 0-1 work split (0 automatic, 1 one tile per workgroup, 2 force stream-K); bit 2: no raw-window
+ * kernels (im2col kernels); bit 3: no tall (256 x 128) raw tile; bits 8-11: stream-K grid = that many x the resident
+ * workgroup slots (1..8; 0 = default 4; > 1 bounds the tail when other kernels such as RCCL's share the chip). */
+enum { PG_SCHED_AUTO = 0, PG_SCHED_TILE_PER_WG = 1, PG_SCHED_FORCE_STREAMK = 2, PG_SCHED_NO_RAW = 4, PG_SCHED_NO_TALL = 8 };
+#define PG_SCHED_OVERSUB(f) (((f) & 15) << 8)
 
 /* nn.Conv1d forward / backward (model.py:77-78; autograd of train.py:61) */
 int pg_conv1d_fwd(const pg_conv_args* a, void* stream);
@@ -75,6 +81,11 @@ int pg_conv1d_wgrad(const pg_conv_args* a, void* stream);
 int pg_convt1d_fwd(const pg_conv_args* a, void* stream);
 int pg_convt1d_dgrad(const pg_conv_args* a, void* stream);
 int pg_convt1d_wgrad(const pg_conv_args* a, void* stream);
+/* The launch plan of one of the six calls above WITHOUT launching it (measurement aid; pure function of the arguments):
+ * buf receives "kernel<template args>|grid=G|tiles=T|slabs=S|split=0/1", the kernel named as rocprofv3 reports it. */
+enum { PG_OP_CONV1D_FWD = 0, PG_OP_CONV1D_DGRAD = 1, PG_OP_CONV1D_WGRAD = 2,
+       PG_OP_CONVT1D_FWD = 3, PG_OP_CONVT1D_DGRAD = 4, PG_OP_CONVT1D_WGRAD = 5 };
+int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, int32_t buflen);
 
 /* Train-mode batch norm over (B, L) per channel (model.py:81,83 applied to 3-D tensors; eps 1e-5, momentum
  * 0.1; biased variance normalises, unbiased variance goes to running_var). */
@@ -121,13 +132,11 @@ int pg_adam_step(const pg_adam_args* a, void* stream);
  * n_frames = 1 + n_samples / hop, reflect padding n_fft/2, periodic Hann.  n_fft: power of two in [32, 4096]. */
 typedef struct pg_stft_args {
     int32_t n_signals, n_samples, n_fft, hop, n_frames, polar;
-    const float* y; float* out;
+    int32_t single_frame;   /* transform schedule: 0 (default) = 4 frames per workgroup, real FFT through an n_fft/2-point radix-4 */
+    int32_t _pad0;          /*   transform (n_fft <= 2048; longer always take the other path); 1 = one frame per workgroup,       */
+    const float* y; float* out; /* full-length radix-2.  Same framing; they differ in fp32 rounding only (tests, measurements).   */
 } pg_stft_args;
 int pg_stft(const pg_stft_args* a, void* stream);
-/* Transform schedule of pg_stft / pg_istft: 0 (default) = 4 frames per workgroup, real FFT through an n_fft/2-point radix-4
- * transform (n_fft <= 2048; longer transforms always take the other path); 1 = one frame per workgroup, full-length radix-2
- * transform.  Both follow the same framing; they differ in fp32 rounding only.  Process-wide; for tests and measurements. */
-int pg_stft_set_mode(int32_t single_frame);
 /* The integer framing map alone (bit-exact contract): idx[t, k] = sample index of tap k of frame t. */
 int pg_stft_frame_index(int32_t n_samples, int32_t n_fft, int32_t hop, int32_t n_frames, int32_t* idx, void* stream);
 
@@ -141,6 +150,7 @@ int pg_polar(const pg_polar_args* a, void* stream);
  * a, b: (n_signals, bins, n_frames) with the given batch strides; audio (n_signals, hop * (n_frames - 1)). */
 typedef struct pg_istft_args {
     int32_t n_signals, bins, n_frames, hop, mode, normalize;
+    int32_t single_frame; int32_t _pad0;   /* transform schedule, as in pg_stft_args */
     const float* a; int64_t a_bs; const float* b; int64_t b_bs;
     float* audio;
     void* workspace; int64_t workspace_bytes;

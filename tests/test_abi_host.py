@@ -23,12 +23,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in phasegen.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
-    assert lib.pg_version() == 100
+    assert lib.pg_version() == 200
 
 
 def test_struct_sizes_match_the_header_layout():
     from phasegen import _lib
-    assert ctypes.sizeof(_lib.ConvArgs) == 8 * 4 + 8 + 8 + 4 + 4 + 8 + 4 * 16 + 8 + 8 + 8 + 8 + 24 + 16   # 208
+    assert ctypes.sizeof(_lib.ConvArgs) == 8 * 4 + 8 + 8 + 4 + 4 + 8 + 4 * 16 + 8 + 8 + 8 + 8 + 24 + 16   # 200
+    assert _lib.ConvArgs.precision.offset == 52 and _lib.ConvArgs.schedule.offset == 148    # the two former pad words
+    assert ctypes.sizeof(_lib.StftArgs) == 48 and ctypes.sizeof(_lib.IstftArgs) == 88
     assert ctypes.sizeof(_lib.AdamArgs) == 8 + 4 * 8 + 5 * 8 + 8
     assert ctypes.sizeof(_lib.LossArgs) == 16 + 4 * 8 + 8 + 8
 
@@ -52,6 +54,79 @@ def test_argument_errors_are_reported_without_a_gpu():
     ad = _lib.AdamArgs()
     ad.n, ad.p, ad.g, ad.m, ad.v, ad.step = 4, 16, 16, 16, 16, 0
     assert lib.pg_adam_step(ctypes.byref(ad), None) == -2                 # step is 1-based
+
+
+def test_abi_keeps_no_process_wide_state():
+    """'keeps no global mutable state => re-entrant and thread-safe per stream'.  Precision, schedule and the
+    FFT schedule are struct fields; no setter is exported and no translation unit defines a mutable namespace-scope int."""
+    from phasegen import _lib
+    lib = _lib.load()
+    for gone in ("pg_conv_set_precision", "pg_conv_set_schedule", "pg_conv_set_oversubscribe", "pg_stft_set_mode"):
+        assert not hasattr(lib, gone), gone
+    csrc = os.path.join(ROOT, "unet-phasegen_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            for ln in open(os.path.join(csrc, f)):
+                assert not re.match(r"^(static\s+)?(int|bool|long|unsigned|float)\s+g_\w+\s*(=|;)", ln), (f, ln)
+    assert "PHASEGEN_CONV_PRECISION" not in open(os.path.join(ROOT, "unet-phasegen_amd", "phasegen", "_lib.py")).read()
+
+
+def _u0_args(lib, precision=0, schedule=0):
+    from phasegen import _lib
+    a = _lib.ConvArgs()
+    a.B, a.Cin, a.Cout, a.Lin, a.Lout, a.k, a.stride, a.pad = 64, 4096, 2048, 129, 256, 32, 2, 16
+    a.x = a.w = a.y = a.dy = a.dx = a.dw = 4096                      # never dereferenced: describe launches nothing
+    a.x_bs = a.dx_bs = 4096 * 129
+    a.y_bs = a.dy_bs = 2048 * 256
+    a.workspace, a.workspace_bytes = 4096, lib.pg_workspace_bytes_conv()
+    a.precision, a.schedule = precision, schedule
+    return a
+
+
+def test_per_call_knobs_are_validated_and_steer_the_launch_plan():
+    """pg_conv_describe is a pure function of the arguments (runs without a GPU): the per-call precision / schedule fields
+    pick the kernel, and bad values are refused with PG_ERR_*."""
+    from phasegen import _lib, ops
+    lib = _lib.load()
+    d = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_FWD)
+    assert d.startswith("conv_raw_kernel<32, 2, true, 0, 2>|") and "split=1" in d
+    assert ops.conv_describe(_u0_args(lib, precision=1), _lib.OP_CONVT1D_FWD).startswith("conv_raw_kernel<32, 2, true, 1, 2>|")
+    assert ops.conv_describe(_u0_args(lib, precision=2), _lib.OP_CONVT1D_WGRAD).startswith("conv_g_raw_kernel<32, 2, 2>|")
+    assert ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_NO_RAW), _lib.OP_CONVT1D_DGRAD).startswith("conv_f_kernel<32, 2, 0>|")
+    one = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_TILE_PER_WG), _lib.OP_CONVT1D_FWD)
+    assert "split=0" in one and "grid=1024|tiles=1024" in one
+    g4 = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_FWD)
+    g1 = ops.conv_describe(_u0_args(lib, schedule=1 << 8), _lib.OP_CONVT1D_FWD)       # oversubscribe factor 1
+    assert "grid=2048" in g4 and "grid=512" in g1
+    buf = ctypes.create_string_buffer(256)
+    assert lib.pg_conv_describe(ctypes.byref(_u0_args(lib, precision=3)), 3, buf, 256) == -4      # PG_ERR_UNSUPPORTED
+    assert lib.pg_conv_describe(ctypes.byref(_u0_args(lib, schedule=3)), 3, buf, 256) == -2       # PG_ERR_SHAPE
+    assert lib.pg_conv_describe(ctypes.byref(_u0_args(lib, schedule=9 << 8)), 3, buf, 256) == -2
+    assert lib.pg_conv_describe(ctypes.byref(_u0_args(lib)), 7, buf, 256) == -4
+    assert lib.pg_conv1d_fwd(ctypes.byref(_u0_args(lib, precision=5)), None) != 0
+
+
+def test_thread_defaults_are_thread_local():
+    """ops.set_conv_precision / set_conv_schedule are per-THREAD Python defaults that are passed per call (pg_conv_args)."""
+    import threading
+    from phasegen import ops
+    ops.set_conv_precision("bf16")
+    ops.set_conv_schedule(4)
+    seen = {}
+
+    def other():
+        seen["p"], seen["s"] = ops._tls.precision, ops._tls.schedule
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    try:
+        assert (ops._tls.precision, ops._tls.schedule) == (1, 4) and seen == {"p": 0, "s": 0}
+        with ops.conv_options(precision="fp32", schedule=0):
+            assert (ops._tls.precision, ops._tls.schedule) == (0, 0)
+        assert (ops._tls.precision, ops._tls.schedule) == (1, 4)
+    finally:
+        ops.set_conv_precision("fp32")
+        ops.set_conv_schedule(0)
 
 
 def test_frame_plan_and_arena_layout():

@@ -1,0 +1,116 @@
+"""End-to-end parity at the reference's REAL width against the oracle, on the same tensors.
+
+The reference trains ``UNetModel(1024, 2048)`` (train.py:15).  The committed goldens pin forward + backward + Adam end to
+end only at C <= 16 (plus one full-width forward, G6); the raw-window / stream-K kernel paths only engage at large shapes.
+Here the oracle (oracle/unet_ref.py, pinned to the imported reference by tests/golden/) runs the SAME step on the GPU
+box's host cores and everything the step produces is compared:
+
+  * C = 1024, L = 256, B = 2  (train.py:41-62 at the BASELINE tile; the oracle leg is a few seconds of CPU)
+  * C = 512,  L = 256, B = 1  (BASELINE configs[0]'s honest 1024-FFT / 256-hop variant: 512 bins)
+  * C = 1024, L = 256, B = 32 forward only (BASELINE configs[1]) -- the whole output tensor and all 14 intermediates
+
+Tolerances (relative to each tensor's max-abs, fp32 on both sides; measured values in DESIGN.md §5a): loss 1e-5, forward
+tensors 1e-4 (BASELINE.json: "within 1e-4 rel fp32"), gradients 2e-4, Adam exp_avg 2e-4, exp_avg_sq 4e-4 (g squared),
+BatchNorm running statistics 1e-4, updated parameters compared where |g| is far above Adam's eps (the first step is
+-lr * g / (|g| + eps)).
+"""
+import numpy as np
+import pytest
+import torch
+
+from phasegen import detgen
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def oracle_state(pn):
+    from oracle import unet_ref
+    po = unet_ref.to_torch(pn)
+    stats = {k: po[k] for k in po if "running" in k or "num_batches" in k}
+    pp = {k: po[k] for k in detgen.param_order()}
+    ost = unet_ref.new_opt_state(pp)
+    pp.update(stats)
+    return pp, ost, stats
+
+
+@pytest.mark.parametrize("C,L,B", [(1024, 256, 2), (512, 256, 1)], ids=["C1024-L256-B2", "C512-L256-B1"])
+def test_train_step_full_width_vs_oracle(C, L, B):
+    from oracle import unet_ref
+    from phasegen.model import UNetModel
+    from phasegen.trainer import Trainer
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+    pn = detgen.make_params(C, seed=0)
+    batch = torch.from_numpy(detgen.make_batch(B, C, L, seed=1))
+    model = UNetModel(C, 2 * C, precision="fp32").load_numpy(pn)
+    tr = Trainer(model, lr=1e-3)
+    p_before = {k: model.engine.arena.p(k).clone() for k in detgen.param_order()}
+    losses = tr.step(batch.cuda()).cpu().numpy()
+    eng = model.engine
+
+    pp, ost, stats = oracle_state(pn)
+    cap = {}
+    with torch.no_grad():                                       # forward intermediates (separate no-grad pass: cheap)
+        unet_ref.unet_forward({k: v for k, v in pp.items()}, batch[:, 0], capture=cap)
+    lo, ao, mo, grads = unet_ref.train_step(pp, batch, ost, stats)
+
+    err = {}
+    want = np.array([lo.item(), ao.item(), mo.item()])
+    err["loss"] = float(np.max(np.abs(losses - want) / np.abs(want)))
+    inter = eng.intermediates()
+    err["out"] = relmax(inter["out"], cap["out"])
+    for k in ("c1", "c2", "r3", "r2", "r1", "r0"):              # raw conv outputs at every level
+        err["act/" + k] = relmax(inter[k], cap[k])
+    for k in detgen.param_order():
+        err["grad/" + k] = relmax(eng.arena.g(k), grads[k])
+        err["m/" + k] = relmax(eng.arena.view(k, tr.optim.m), ost["m"][k])
+        err["v/" + k] = relmax(eng.arena.view(k, tr.optim.v), ost["v"][k])
+        w = grads[k]
+        sig = (w.abs() > 1e-4 * w.abs().max())
+        dp_dev = (eng.arena.p(k).cpu() - p_before[k].cpu()) * sig
+        dp_ref = (pp[k].detach() - torch.from_numpy(pn[k])) * sig
+        err["dp/" + k] = float((dp_dev - dp_ref).abs().max() / 1e-3)          # in units of lr: the update is +-lr
+    for k in detgen.BN_KEYS:
+        err["rm/" + k] = relmax(eng.arena.buffers[k + ".running_mean"], stats[k + ".running_mean"])
+        err["rv/" + k] = relmax(eng.arena.buffers[k + ".running_var"], stats[k + ".running_var"])
+        assert int(eng.arena.buffers[k + ".num_batches_tracked"]) == int(stats[k + ".num_batches_tracked"]) == 1
+    worst = {g: max((v, k) for k, v in err.items() if k.startswith(g)) for g in ("loss", "out", "act/", "grad/", "m/", "v/", "dp/", "rm/", "rv/")}
+    print(f"\nfull-width parity C={C} L={L} B={B}: " + ", ".join(f"{g}{v[0]:.2e}" for g, v in worst.items()))
+    tol = {"loss": 1e-5, "out": 1e-4, "act/": 1e-4, "grad/": 2e-4, "m/": 2e-4, "v/": 4e-4, "dp/": 2e-2, "rm/": 1e-4, "rv/": 1e-4}
+    bad = {k: v for k, v in err.items() if v > next(t for g, t in tol.items() if k.startswith(g))}
+    assert not bad, (bad, worst)
+
+
+def test_forward_batch32_full_width_vs_oracle():
+    """BASELINE configs[1]: batch 32 x 1024 bins x 256 frames, forward only (train-mode BatchNorm as the reference always
+    runs it).  The oracle computes the same forward on the host (~4 TFLOP); the WHOLE output and every intermediate of the
+    device are compared with it at 1e-4 of max-abs."""
+    from oracle import unet_ref
+    from phasegen.model import UNetModel
+    C, L, B = 1024, 256, 32
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+    pn = detgen.make_params(C, seed=0)
+    x = torch.from_numpy(detgen.make_batch(B, C, L, seed=3)[:, 0].copy())
+    model = UNetModel(C, 2 * C, precision="fp32").load_numpy(pn)
+    with torch.no_grad():
+        out = model.forward(x.cuda())
+        inter = {k: v.clone() for k, v in model.engine.intermediates().items()}
+        cap = {}
+        po = unet_ref.to_torch(pn)
+        del pn
+        want = unet_ref.unet_forward(po, x, capture=cap)
+    assert tuple(out.shape) == (B, 2 * C, L)
+    errs = {"out": relmax(out, want)}
+    for k, v in inter.items():
+        if ":" in k:
+            act, name = k.split(":")
+            ref = torch.nn.functional.leaky_relu(cap[name], 0.2) if act == "leaky" else torch.relu(cap[name])
+        else:
+            ref = cap[k]
+        errs[k] = relmax(v, ref)
+    print("\nconfigs[1] forward parity: " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert max(errs.values()) < 1e-4, errs

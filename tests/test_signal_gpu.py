@@ -183,7 +183,7 @@ def test_loader_semantics(tmp_path):
     r0 = get_fft_npy_loader(p, batch_size=2, precon=True, rank=0, world=2, seed=7)
     r1 = get_fft_npy_loader(p, batch_size=2, precon=True, rank=1, world=2, seed=7)
     n0 = sum(b[0].shape[0] for b in r0); n1 = sum(b[0].shape[0] for b in r1)
-    assert (n0, n1) == (3, 2)                                                          # clips r::W of one shared permutation
+    assert (n0, n1) == (2, 2)            # clips r::W of one shared permutation cut to whole global batches (2 x 2 of 5 clips)
     with pytest.raises(AssertionError):
         get_fft_npy_loader([str(tmp_path / "nope.npy")])
 
@@ -200,8 +200,12 @@ def test_griffin_lim_vs_oracle(n_fft, hop, frames, n_iter):
     want_a, want_s, want_l = signal_ref.griffin_lim(mag, n_fft, hop, n_iter, init)
     got_a, got_s, got_l = audio.griffin_lim(mag, n_fft, hop, n_iter, init=init)
     assert got_a.shape == want_a.shape == (n,) and got_s.shape == want_s.shape
-    assert relmax(got_a, want_a) < 2e-3
-    assert np.max(np.abs(got_s - want_s)) < 2e-3 * np.max(np.abs(want_s))
+    # Tolerance: each iteration is stft -> angle -> istft; the device's inverse is an fp32 GEMM against a 2046-point synthesis
+    # matrix rounded to fp32 (the oracle works in float64), and angle() of small bins amplifies ~1e-6 errors: they compound over
+    # the iterations.  Measured 1e-4 .. 6e-4 for these cases (2-4 iterations); STFT and ISTFT alone hold 2e-5 (tests above).
+    ea, es = relmax(got_a, want_a), float(np.max(np.abs(got_s - want_s)) / np.max(np.abs(want_s)))
+    print(f"\ngriffin_lim n_fft={n_fft} iters={n_iter}: audio {ea:.1e} spec {es:.1e} loss {abs(got_l - want_l) / abs(want_l):.1e}")
+    assert ea < 2e-3 and es < 2e-3
     assert abs(got_l - want_l) < 2e-3 * abs(want_l)
     assert abs(np.max(np.abs(got_a)) - 1.0) < 1e-6
     a2, _, _ = audio.griffin_lim(mag, n_fft, hop, n_iter, seed=7)      # seeded random start: reproducible
@@ -217,15 +221,27 @@ def test_preproc_chunker_matches_reference_algorithm(tmp_path):
     t_slice = int(sec * rsr)
     tracks = [detgen.make_clip(1300, seed=80), detgen.make_clip(700, seed=81)]
     train, val = preproc.build_dataset(tracks, sec, rsr, n_fft, hop, n_random=2, n_val=3, seed=5, out_dir=str(tmp_path))
-    # numpy restatement
+    # numpy restatement of preproc_mdb.py:66-97 written out HERE (not through phasegen.preproc): one aligned chunk every
+    # t_slice samples, each followed by n_random crops starting at randint(0, a_len - t_slice // 1.3); a tail shorter than
+    # t_slice is zero-padded (:86-88).  The reference draws from the global np.random state; the product takes a Generator,
+    # so the restatement draws from an identically seeded one in the same order.
     rng = np.random.default_rng(5)
-    chunks = []
+    chunks, n_starts = [], 0
     for a in tracks:
-        for st in preproc.chunk_starts(len(a), t_slice, 2, rng):
+        a_len = len(a)
+        bnd = a_len - t_slice // 1.3                            # preproc_mdb.py:70 (float floor-division, kept as is)
+        starts = []
+        for i in range(0, a_len, t_slice):                      # :73
+            starts.append(i)
+            for _ in range(2):                                  # n_random = 2, :77-80
+                starts.append(int(rng.integers(0, bnd)))
+        n_starts += len(starts)
+        for st in starts:
             c = a[st:st + t_slice]
             if len(c) < t_slice:
                 c = np.pad(c, (0, t_slice - len(c)), "constant")
             chunks.append(signal_ref.chunk_and_stft(c, n_fft, hop))
+    assert n_starts == (3 + 2) * 3 and starts[0] == 0 and starts[3] == t_slice      # 1300 -> 3 aligned chunks, 700 -> 2
     x = np.asarray(chunks, dtype=np.float32)
     x = (x - x.mean()) / x.std()
     idx = np.linspace(0, len(x) - 1, len(x), dtype=int)

@@ -110,7 +110,7 @@ __device__ __forceinline__ void dma16s(rsrc_t r, float* lds_wave_uniform, int la
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_wave_uniform, 16, lane_off, uniform_off, 0, 0);
 }
 
-// bf16 operand mode (pg_conv_set_precision(1)): the same fragments -- lane (row, h) already holds k = 8h .. 8h+7 of the
+// bf16 operand mode (pg_conv_args.precision = PG_PREC_BF16): the same fragments -- lane (row, h) already holds k = 8h .. 8h+7 of the
 // slab, which is exactly the operand layout of v_mfma_f32_32x32x16_bf16 -- are rounded to bf16 (RNE, v_cvt_pk_bf16_f32)
 // after the activation and one MFMA replaces eight; accumulation stays fp32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -129,7 +129,7 @@ __device__ __forceinline__ void mfma_bf16(const bf16x8 (&A)[MB], const bf16x8 (&
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i], B[j], acc.c[i][j], 0, 0, 0);
 }
-// Split mode (pg_conv_set_precision(2), "bf16x3"): every fp32 operand is written as hi + lo with hi = bf16(x) and
+// Split mode (PG_PREC_BF16X3, "bf16x3"): every fp32 operand is written as hi + lo with hi = bf16(x) and
 // lo = bf16(x - hi) (the subtraction is exact), and the product is taken as hi*hi' + hi*lo' + lo*hi' on the bf16 pipe:
 // three MFMAs at 1/16 of the fp32 cost each.  Dropped: lo*lo' and the two representation residuals, each <= 2^-18 of the
 // product, i.e. a relative error of ~1e-5 per product against fp32's 6e-8 -- inside the 1e-4 parity bound, NOT fp32.
@@ -409,7 +409,7 @@ enum Kind { KIND_F, KIND_T, KIND_G };
 
 }  // namespace
 
-// Kernel launchers, one per translation unit.  `prec` = pg_conv_set_precision mode (0 fp32, 1 bf16, 2 bf16x3).
+// Kernel launchers, one per translation unit.  `prec` = pg_conv_args.precision (0 fp32, 1 bf16, 2 bf16x3).
 namespace pgconv {
 hipError_t launch_im2col(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_im2col.hip
 hipError_t launch_raw_ft(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw.hip (F / T, tile 128 x 256)

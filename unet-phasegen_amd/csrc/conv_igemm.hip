@@ -1,6 +1,6 @@
 // conv_igemm.hip -- the six 1-D convolution passes of the U-Net as three implicit-GEMM kernels on the
 // gfx950 matrix cores (default v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain; optional bf16-pipe operand
-// modes, pg_conv_set_precision).
+// modes, pg_conv_args.precision).
 //
 //   F ("forward-shaped"):  Y[b,m,t]  = sum_{q,j}               W[m][q][j] * act(X[b,q,s*t+j-p])
 //        = nn.Conv1d forward (model.py:77-78)            and nn.ConvTranspose1d dgrad
@@ -72,32 +72,45 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-int g_bf16 = 0;         // pg_conv_set_precision: 0 fp32 MFMA, 1 bf16 operands, 2 bf16x3 split (all fp32 accumulate)
-
 constexpr int WG_PER_CU = 2;                    // <= 256 VGPR+AGPR per lane -> 2 waves per SIMD; 48 KB LDS per workgroup
 constexpr int MAX_STREAMK_WG = 2048;            // bound on the persistent grid (sizes the caller's workspace)
 constexpr long WS_PER_WG = 2L * ACC_REGS * NT * 4;   // two partial tiles of 256x128 fp32 per workgroup
 
-// schedule knobs (process-wide; set through pg_conv_set_schedule / pg_conv_set_oversubscribe)
-int g_force_mode = 0;   // work split: 0 automatic, 1 one tile per workgroup, 2 force stream-K
-int g_force_raw = 0;    // 1 = never use the raw-window kernels (exercise the im2col kernels)
-int g_no_tall = 0;      // 1 = never use the tall 256 x 128 raw tile
-int g_oversub = 4;      // stream-K grid = up to g_oversub x resident workgroup slots
+// Per-call knobs decoded from pg_conv_args.precision / .schedule (no process-wide state: two streams or threads can run
+// different precisions and schedules concurrently).
+struct Knobs {
+    int prec;         // PG_PREC_*: 0 fp32 MFMA, 1 bf16 operands, 2 bf16x3 split (all fp32 accumulate)
+    int force_mode;   // work split: 0 automatic, 1 one tile per workgroup, 2 force stream-K
+    int no_raw;       // 1 = never use the raw-window kernels (exercise the im2col kernels)
+    int no_tall;      // 1 = never use the tall 256 x 128 raw tile
+    int oversub;      // stream-K grid = up to oversub x resident workgroup slots
+    char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
+};
+int decode_knobs(const pg_conv_args* a, Knobs& k) {
+    if (a->precision < 0 || a->precision > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv: precision must be PG_PREC_FP32, PG_PREC_BF16 or PG_PREC_BF16X3");
+    const int sc = a->schedule;
+    if (sc < 0 || (sc & ~0xf0f) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
+    k.prec = a->precision;
+    k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
+    k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
+    k.desc = nullptr; k.desc_len = 0;
+    return PG_OK;
+}
 
 int cu_count() { return pg_cu_count(); }
 
-// Grid policy.  Default: a persistent stream-K grid of up to g_oversub (4) x the resident workgroup slots, each
+// Grid policy.  Default: a persistent stream-K grid of up to oversub (4) x the resident workgroup slots, each
 // workgroup owning an equal contiguous range of the (tile, slab) space, plus the fixup launch.  Measured on MI355X
 // (tools/contention.py): the oversubscribed split costs nothing on a free chip, removes tile-count quantisation, and --
 // what matters for data-parallel training, where RCCL's collective kernels hold part of the chip during backward --
 // degrades gracefully when slots are taken (16 of 512 slots held: 1x split 33 -> 58 ms, one-tile-per-workgroup 32 -> 43 ms,
 // 4x split 33 -> 37 ms).  Small problems (less than 8 slabs per resident slot, or no workspace) run one tile per
 // workgroup.  mode: 0 auto, 1 force one tile per workgroup, 2 force stream-K (tests).
-int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mode) {
+int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mode, int oversub) {
     const long total = tiles * (long)nslab;
     const long slots = (long)cu_count() * WG_PER_CU;
     long mult = total / (256 * slots);               // whole multiples of the slot count only (a ragged second wave is
-    if (mult > g_oversub) mult = g_oversub;          // worse than none), and >= 256 slabs per workgroup so that partial-
+    if (mult > oversub) mult = oversub;              // worse than none), and >= 256 slabs per workgroup so that partial-
     if (mult < 1) mult = 1;                          // tile traffic stays negligible
     long G = slots * mult;
     if (G > MAX_STREAMK_WG) G = (MAX_STREAMK_WG / slots) * slots;
@@ -109,8 +122,8 @@ int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mo
 }
 
 // raw-window kernels: supported (k, s) pairs and the window-length bound
-bool raw_supported(Kind kind, const IgemmParams& p, int tn = RBN) {
-    if (g_force_raw == 1) return false;
+bool raw_supported(Kind kind, const IgemmParams& p, const Knobs& kn, int tn = RBN) {
+    if (kn.no_raw == 1) return false;
     int kwp, sc, lcol;
     if (kind == KIND_F) {
         if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
@@ -127,15 +140,15 @@ bool raw_supported(Kind kind, const IgemmParams& p, int tn = RBN) {
     return sc * (tn - 1) + tj + RG * (nseg_max - 1) + (kind == KIND_T ? tj : 0) <= (sc == 1 ? RS1 : RS2);
 }
 
-int launch(Kind kind, IgemmParams& p, long rows, long cols, long Ktot, long ws_bytes, hipStream_t st) {
-    bool raw = raw_supported(kind, p);
+int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, long Ktot, long ws_bytes, hipStream_t st) {
+    bool raw = raw_supported(kind, p, kn);
     // F / T problems whose columns the tall 256 x 128 tile covers with at least 3 % fewer computed ones take it: small-batch
     // inference above all (a 128 x 256 tile over 65 columns is 3/4 idle MFMA work per weight byte), and training shapes such as
     // N = 16 x 65 (5 wide tiles = 1280 columns vs 9 tall = 1152: +15 % measured) or 64 x 30.  On ties the wide tile wins (it
     // runs two slabs per barrier; measured 1-7 % faster at equal column counts).
     const long cols_wide = (cols + RBN - 1) / RBN * RBN, cols_tall = (cols + RBN / 2 - 1) / (RBN / 2) * (RBN / 2);
-    const bool tall = kind != KIND_G && g_force_raw == 0 && g_no_tall == 0 && cols_tall * 100 <= cols_wide * 97 &&
-                      raw_supported(kind, p, RBN / 2);
+    const bool tall = kind != KIND_G && kn.no_raw == 0 && kn.no_tall == 0 && cols_tall * 100 <= cols_wide * 97 &&
+                      raw_supported(kind, p, kn, RBN / 2);
     if (tall) raw = true;
     const int bm = tall ? 2 * RBM : (raw ? RBM : BM), bn = tall ? RBN / 2 : (raw ? RBN : BN);
     p.tilesM = (int)((rows + bm - 1) / bm);
@@ -143,12 +156,21 @@ int launch(Kind kind, IgemmParams& p, long rows, long cols, long Ktot, long ws_b
     p.nslab = (int)((Ktot + BK - 1) / BK);
     const long tiles = (long)p.tilesM * p.tilesN;
     if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");   // the fixup launches 8 workgroups per tile
-    const int grid = pick_grid(tiles, p.nslab, p, ws_bytes, g_force_mode);
+    const int grid = pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub);
+    if (kn.desc) {      // the kernel this call would launch, named as rocprofv3 names it (profiles/*_kernel_stats.csv)
+        const bool spec = (p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || (p.k == 5 && p.s == 2);
+        char name[96];
+        if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_raw_kernel<%d, %d, %d>", p.k, p.s, kn.prec);
+        else if (raw) snprintf(name, sizeof name, "conv_raw_kernel<%d, %d, %s, %d, %d>", p.k, p.s, kind == KIND_T ? "true" : "false", kn.prec, tall ? 1 : 2);
+        else snprintf(name, sizeof name, "conv_%c_kernel<%d, %d, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), spec ? p.k : 0, spec ? p.s : 0, kn.prec);
+        snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d", name, grid, tiles, p.nslab, grid != tiles);
+        return PG_OK;
+    }
     hipError_t e;
-    if (raw && kind == KIND_G) e = pgconv::launch_raw_g(p, grid, st, g_bf16);
-    else if (tall) e = pgconv::launch_raw_ft_tall(kind, p, grid, st, g_bf16);
-    else if (raw) e = pgconv::launch_raw_ft(kind, p, grid, st, g_bf16);
-    else e = pgconv::launch_im2col(kind, p, grid, st, g_bf16);
+    if (raw && kind == KIND_G) e = pgconv::launch_raw_g(p, grid, st, kn.prec);
+    else if (tall) e = pgconv::launch_raw_ft_tall(kind, p, grid, st, kn.prec);
+    else if (raw) e = pgconv::launch_raw_ft(kind, p, grid, st, kn.prec);
+    else e = pgconv::launch_im2col(kind, p, grid, st, kn.prec);
     if (e == hipSuccess && grid != tiles) {
         if (tall) {
             if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
@@ -203,8 +225,10 @@ int set_extents(IgemmParams& p, long xC, long xL, long ptC, long ptL) {
 }  // namespace
 
 // nn.Conv1d forward: F kernel with M = Cout, Q = Cin.
-extern "C" int pg_conv1d_fwd(const pg_conv_args* a, void* stream) {
+static int run_conv1d_fwd(const pg_conv_args* a, void* stream, char* desc, int desc_len) {
     if (int e = check_geom(a, false)) return e;
+    Knobs kn; if (int e = decode_knobs(a, kn)) return e;
+    kn.desc = desc; kn.desc_len = desc_len;
     if (!a->x || !a->w || !a->y) return pg_fail(PG_ERR_NULL, "conv1d_fwd: x, w, y required");
     IgemmParams p = {};
     p.y_slope = act_slope(a->y_act); p.y2 = a->y2; p.y2_bs = a->y2_bs; p.y2_slope = act_slope(a->y2_act);
@@ -213,12 +237,14 @@ extern "C" int pg_conv1d_fwd(const pg_conv_args* a, void* stream) {
     p.act_x = a->x_act;
     if (int e = set_extents(p, p.Q, p.Lx, 0, 0)) return e;
     p.ws = (float*)a->workspace;
-    return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (long)p.Q * p.k, a->workspace_bytes, (hipStream_t)stream);
+    return launch(KIND_F, p, kn, p.M, (long)p.B * p.Ly, (long)p.Q * p.k, a->workspace_bytes, (hipStream_t)stream);
 }
 
 // nn.ConvTranspose1d dgrad: dx[b,c,i] = sum_{o,j} w[c][o][j] dy[b,o,s*i+j-p]  -> F kernel with M = Cin, Q = Cout.
-extern "C" int pg_convt1d_dgrad(const pg_conv_args* a, void* stream) {
+static int run_convt1d_dgrad(const pg_conv_args* a, void* stream, char* desc, int desc_len) {
     if (int e = check_geom(a, true)) return e;
+    Knobs kn; if (int e = decode_knobs(a, kn)) return e;
+    kn.desc = desc; kn.desc_len = desc_len;
     if (!a->dy || !a->w || !a->dx) return pg_fail(PG_ERR_NULL, "convt1d_dgrad: dy, w, dx required");
     IgemmParams p = {};
     p.y_slope = 1.0f; p.y2_slope = 1.0f;
@@ -228,22 +254,24 @@ extern "C" int pg_convt1d_dgrad(const pg_conv_args* a, void* stream) {
     p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.Ly = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
     if (int e = set_extents(p, p.Q, p.Lx, 0, 0)) return e;
     p.ws = (float*)a->workspace;
-    return launch(KIND_F, p, p.M, (long)p.B * p.Ly, (long)p.Q * p.k, a->workspace_bytes, (hipStream_t)stream);
+    return launch(KIND_F, p, kn, p.M, (long)p.B * p.Ly, (long)p.Q * p.k, a->workspace_bytes, (hipStream_t)stream);
 }
 
-static int launch_t(IgemmParams& p, long ws_bytes, hipStream_t st) {
+static int launch_t(IgemmParams& p, const Knobs& kn, long ws_bytes, hipStream_t st) {
     // tau = s*u + phi - p >= 0 for some phi  <=>  u >= floor(p/s) at the latest; tau <= Ly-1 => u <= (Ly-1+p)/s
     p.u_off = p.p / p.s;
     const int u_max = (p.Ly - 1 + p.p) / p.s;
     p.U = u_max - p.u_off + 1;
     if (p.U <= 0) return pg_fail(PG_ERR_SHAPE, "convT: empty output");
     if (int e = set_extents(p, p.Q, p.Lx, 0, 0)) return e;
-    return launch(KIND_T, p, (long)p.M * p.s, (long)p.B * p.U, (long)p.Q * ((p.k + p.s - 1) / p.s), ws_bytes, st);
+    return launch(KIND_T, p, kn, (long)p.M * p.s, (long)p.B * p.U, (long)p.Q * ((p.k + p.s - 1) / p.s), ws_bytes, st);
 }
 
 // nn.ConvTranspose1d forward: T kernel with M = Cout, Q = Cin.
-extern "C" int pg_convt1d_fwd(const pg_conv_args* a, void* stream) {
+static int run_convt1d_fwd(const pg_conv_args* a, void* stream, char* desc, int desc_len) {
     if (int e = check_geom(a, true)) return e;
+    Knobs kn; if (int e = decode_knobs(a, kn)) return e;
+    kn.desc = desc; kn.desc_len = desc_len;
     if (!a->x || !a->w || !a->y) return pg_fail(PG_ERR_NULL, "convt1d_fwd: x, w, y required");
     IgemmParams p = {};
     p.y_slope = act_slope(a->y_act); p.y2 = a->y2; p.y2_bs = a->y2_bs; p.y2_slope = act_slope(a->y2_act);
@@ -251,12 +279,14 @@ extern "C" int pg_convt1d_fwd(const pg_conv_args* a, void* stream) {
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.Ly = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
     p.act_x = a->x_act;
     p.ws = (float*)a->workspace;
-    return launch_t(p, a->workspace_bytes, (hipStream_t)stream);
+    return launch_t(p, kn, a->workspace_bytes, (hipStream_t)stream);
 }
 
 // nn.Conv1d dgrad: dx[b,c,u] = sum_{o,j,t: s*t+j-p=u} w[o][c][j] dy[b,o,t]  -> T kernel with M = Cin, Q = Cout.
-extern "C" int pg_conv1d_dgrad(const pg_conv_args* a, void* stream) {
+static int run_conv1d_dgrad(const pg_conv_args* a, void* stream, char* desc, int desc_len) {
     if (int e = check_geom(a, false)) return e;
+    Knobs kn; if (int e = decode_knobs(a, kn)) return e;
+    kn.desc = desc; kn.desc_len = desc_len;
     if (!a->dy || !a->w || !a->dx) return pg_fail(PG_ERR_NULL, "conv1d_dgrad: dy, w, dx required");
     IgemmParams p = {};
     p.y_slope = 1.0f; p.y2_slope = 1.0f;
@@ -265,12 +295,14 @@ extern "C" int pg_conv1d_dgrad(const pg_conv_args* a, void* stream) {
     p.mask_mode = a->dx_ref ? a->dx_mask : 0;
     p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.Ly = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
     p.ws = (float*)a->workspace;
-    return launch_t(p, a->workspace_bytes, (hipStream_t)stream);
+    return launch_t(p, kn, a->workspace_bytes, (hipStream_t)stream);
 }
 
 // nn.Conv1d wgrad: dw[o][c][j] = sum_{b,t} dy[b,o,t] act(x)[b,c,s*t+j-p]  -> G with P = dy (M = Cout), Q = x.
-extern "C" int pg_conv1d_wgrad(const pg_conv_args* a, void* stream) {
+static int run_conv1d_wgrad(const pg_conv_args* a, void* stream, char* desc, int desc_len) {
     if (int e = check_geom(a, false)) return e;
+    Knobs kn; if (int e = decode_knobs(a, kn)) return e;
+    kn.desc = desc; kn.desc_len = desc_len;
     if (!a->dy || !a->x || !a->dw) return pg_fail(PG_ERR_NULL, "conv1d_wgrad: dy, x, dw required");
     IgemmParams p = {};
     p.pt = a->dy; p.pt_bs = a->dy_bs; p.LP = a->Lout; p.act_p = PG_ACT_NONE;
@@ -278,12 +310,14 @@ extern "C" int pg_conv1d_wgrad(const pg_conv_args* a, void* stream) {
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
     if (int e = set_extents(p, p.Q, p.Lx, p.M, p.LP)) return e;
     p.ws = (float*)a->workspace;
-    return launch(KIND_G, p, p.M, (long)p.Q * p.k, (long)p.B * p.LP, a->workspace_bytes, (hipStream_t)stream);
+    return launch(KIND_G, p, kn, p.M, (long)p.Q * p.k, (long)p.B * p.LP, a->workspace_bytes, (hipStream_t)stream);
 }
 
 // nn.ConvTranspose1d wgrad: dw[c][o][j] = sum_{b,i} act(x)[b,c,i] dy[b,o,s*i+j-p]  -> G with P = x (M = Cin), Q = dy.
-extern "C" int pg_convt1d_wgrad(const pg_conv_args* a, void* stream) {
+static int run_convt1d_wgrad(const pg_conv_args* a, void* stream, char* desc, int desc_len) {
     if (int e = check_geom(a, true)) return e;
+    Knobs kn; if (int e = decode_knobs(a, kn)) return e;
+    kn.desc = desc; kn.desc_len = desc_len;
     if (!a->dy || !a->x || !a->dw) return pg_fail(PG_ERR_NULL, "convt1d_wgrad: dy, x, dw required");
     IgemmParams p = {};
     p.pt = a->x; p.pt_bs = a->x_bs; p.LP = a->Lin; p.act_p = a->x_act;
@@ -291,35 +325,33 @@ extern "C" int pg_convt1d_wgrad(const pg_conv_args* a, void* stream) {
     p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
     if (int e = set_extents(p, p.Q, p.Lx, p.M, p.LP)) return e;
     p.ws = (float*)a->workspace;
-    return launch(KIND_G, p, p.M, (long)p.Q * p.k, (long)p.B * p.LP, a->workspace_bytes, (hipStream_t)stream);
+    return launch(KIND_G, p, kn, p.M, (long)p.Q * p.k, (long)p.B * p.LP, a->workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int pg_conv1d_fwd(const pg_conv_args* a, void* stream) { return run_conv1d_fwd(a, stream, nullptr, 0); }
+extern "C" int pg_conv1d_dgrad(const pg_conv_args* a, void* stream) { return run_conv1d_dgrad(a, stream, nullptr, 0); }
+extern "C" int pg_conv1d_wgrad(const pg_conv_args* a, void* stream) { return run_conv1d_wgrad(a, stream, nullptr, 0); }
+extern "C" int pg_convt1d_fwd(const pg_conv_args* a, void* stream) { return run_convt1d_fwd(a, stream, nullptr, 0); }
+extern "C" int pg_convt1d_dgrad(const pg_conv_args* a, void* stream) { return run_convt1d_dgrad(a, stream, nullptr, 0); }
+extern "C" int pg_convt1d_wgrad(const pg_conv_args* a, void* stream) { return run_convt1d_wgrad(a, stream, nullptr, 0); }
+
+// The launch plan of a conv call without launching it: "kernel<template args>|grid=..|tiles=..|slabs=..|split=0/1", the kernel
+// named as rocprofv3 reports it.  Pure function of the arguments (same checks as the real call); bench.py uses it to group
+// its per-launch timings by kernel so that its roofline numbers can be recomputed from profiles/*_kernel_stats.csv.
+extern "C" int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, int32_t buflen) {
+    if (!buf || buflen < 128) return pg_fail(PG_ERR_NULL, "conv_describe: buf of >= 128 bytes required");
+    buf[0] = 0;
+    switch (op) {
+        case PG_OP_CONV1D_FWD: return run_conv1d_fwd(a, nullptr, buf, buflen);
+        case PG_OP_CONV1D_DGRAD: return run_conv1d_dgrad(a, nullptr, buf, buflen);
+        case PG_OP_CONV1D_WGRAD: return run_conv1d_wgrad(a, nullptr, buf, buflen);
+        case PG_OP_CONVT1D_FWD: return run_convt1d_fwd(a, nullptr, buf, buflen);
+        case PG_OP_CONVT1D_DGRAD: return run_convt1d_dgrad(a, nullptr, buf, buflen);
+        case PG_OP_CONVT1D_WGRAD: return run_convt1d_wgrad(a, nullptr, buf, buflen);
+    }
+    return pg_fail(PG_ERR_UNSUPPORTED, "conv_describe: op must be a PG_OP_* value");
 }
 
 // Workspace a caller should hand to the conv entry points (pg_conv_args.workspace) so that badly quantised tile counts
 // can be balanced over all CUs (stream-K).  Without it every call falls back to one-tile-per-workgroup scheduling.
 extern "C" int64_t pg_workspace_bytes_conv(void) { return (int64_t)MAX_STREAMK_WG * WS_PER_WG; }
-
-// Test hook: 0 = automatic schedule, 1 = force one tile per workgroup, 2 = force stream-K (needs a workspace).
-extern "C" int pg_conv_set_schedule(int mode) {
-    // bits 0-1: 0 automatic split, 1 one tile per workgroup, 2 force stream-K;  bit 2: disable the raw-window kernels
-    if (mode < 0 || mode > 15 || (mode & 3) == 3) return pg_fail(PG_ERR_SHAPE, "conv_set_schedule: bad mode");
-    g_force_mode = mode & 3;
-    g_force_raw = (mode >> 2) & 1;
-    g_no_tall = (mode >> 3) & 1;
-    return PG_OK;
-}
-
-// Stream-K launches one workgroup per resident slot and gives each the same amount of work.  When other kernels hold part
-// of the chip (RCCL's collective kernels during data-parallel backward), the workgroups that do not fit run as a second
-// wave and the launch takes up to twice as long.  factor > 1 splits the work over factor x more, proportionally shorter
-// workgroups, which bounds that tail at 1/factor of a workgroup's duration (at the price of more partial tiles).
-extern "C" int pg_conv_set_precision(int32_t mode) {
-    if (mode < 0 || mode > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv_set_precision: 0 (fp32), 1 (bf16 operands) or 2 (bf16x3 split)");
-    g_bf16 = mode;
-    return PG_OK;
-}
-
-extern "C" int pg_conv_set_oversubscribe(int factor) {
-    if (factor < 1 || factor > 8) return pg_fail(PG_ERR_SHAPE, "conv_set_oversubscribe: factor must be 1..8");
-    g_oversub = factor;
-    return PG_OK;
-}

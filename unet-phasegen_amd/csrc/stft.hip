@@ -586,7 +586,6 @@ bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 // the batched kernels hold 2 x SF frames of n_fft/2 complex points plus the twiddle table: 72 KB at n_fft = 2048
 constexpr int BATCHED_MAX_NFFT = 2048;
-int g_stft_single = 0;                     // pg_stft_set_mode(1): one frame per workgroup, full-length radix-2 transform
 size_t batched_lds(int n_fft) { return (size_t)(2 * SF * (n_fft / 2) + 3 * tw_len(n_fft / 2)) * sizeof(float2); }
 int batched_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (2 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }
 hipError_t batched_lds_ready() {
@@ -607,7 +606,7 @@ extern "C" int pg_stft(const pg_stft_args* a, void* stream) {
     if (a->n_frames != 1 + a->n_samples / a->hop) return pg_fail(PG_ERR_SHAPE, "stft: n_frames must equal 1 + n_samples / hop");
     hipError_t e = batched_lds_ready();
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
-    if (a->n_fft <= BATCHED_MAX_NFFT && !g_stft_single) {
+    if (a->n_fft <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
         hipLaunchKernelGGL(stft_frames_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
     } else {
@@ -617,8 +616,6 @@ extern "C" int pg_stft(const pg_stft_args* a, void* stream) {
     e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
 }
-
-extern "C" int pg_stft_set_mode(int32_t single_frame) { g_stft_single = single_frame ? 1 : 0; return PG_OK; }
 
 extern "C" int pg_stft_frame_index(int32_t n_samples, int32_t n_fft, int32_t hop, int32_t n_frames, int32_t* idx, void* stream) {
     if (!idx) return pg_fail(PG_ERR_NULL, "stft_frame_index: idx required");
@@ -653,7 +650,7 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
     float* frames = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));
     hipError_t e;
     if ((e = batched_lds_ready()) != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
-    if (N <= BATCHED_MAX_NFFT && !g_stft_single) {
+    if (N <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
         hipLaunchKernelGGL(istft_frames4_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(N), st, *a, frames);
     } else {

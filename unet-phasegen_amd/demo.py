@@ -28,7 +28,7 @@ def main():
     parser.add_argument("--dataset_dir", default="dataset")
     parser.add_argument("--out_dir", default="demo")
     parser.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
-                    help="MFMA operand mode of the convolutions (pg_conv_set_precision): fp32 = the reference's arithmetic")
+                    help="MFMA operand mode of the convolutions (pg_conv_args.precision): fp32 = the reference's arithmetic")
     args = parser.parse_args()
 
     import numpy as np
@@ -36,15 +36,13 @@ def main():
     from scipy.io import wavfile
     from data import get_fft_npy_loader
     from utils import generate_audio
-    from phasegen import ops as _ops
-    _ops.set_conv_precision(args.precision)
     from cycleGAN import UNetModel
     from phasegen import audio as pg_audio
 
     torch.cuda.set_device(args.gpu)
     loader = get_fft_npy_loader([os.path.join(args.dataset_dir, args.genre + "_audio_val.npy")], [0, 1],
                                 batch_size=args.n_songs, precon=True)
-    model = UNetModel(args.channels, args.channels * 2, gpu_ids=[args.gpu]).cuda(args.gpu)
+    model = UNetModel(args.channels, args.channels * 2, gpu_ids=[args.gpu], precision=args.precision).cuda(args.gpu)
     model.load(args.weight)
     data = loader.__iter__().__next__()[0]
     os.makedirs(args.out_dir, exist_ok=True)

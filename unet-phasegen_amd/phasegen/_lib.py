@@ -11,6 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphasegen.so")
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2           # pg_conv_args.precision
+OP_CONV1D_FWD, OP_CONV1D_DGRAD, OP_CONV1D_WGRAD, OP_CONVT1D_FWD, OP_CONVT1D_DGRAD, OP_CONVT1D_WGRAD = range(6)   # pg_conv_describe
+SCHED_AUTO, SCHED_TILE_PER_WG, SCHED_FORCE_STREAMK, SCHED_NO_RAW, SCHED_NO_TALL = 0, 1, 2, 4, 8   # pg_conv_args.schedule bits
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -18,14 +21,14 @@ c_float_p = C.c_void_p  # device pointers travel as integers
 class ConvArgs(C.Structure):
     _fields_ = [("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("Lin", C.c_int32), ("Lout", C.c_int32),
                 ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-                ("x", C.c_void_p), ("x_bs", C.c_int64), ("x_act", C.c_int32), ("_pad0", C.c_int32),
+                ("x", C.c_void_p), ("x_bs", C.c_int64), ("x_act", C.c_int32), ("precision", C.c_int32),
                 ("w", C.c_void_p),
                 ("y", C.c_void_p), ("y_bs", C.c_int64),
                 ("dy", C.c_void_p), ("dy_bs", C.c_int64),
                 ("dx", C.c_void_p), ("dx_bs", C.c_int64),
                 ("dx_add", C.c_void_p), ("dx_add_bs", C.c_int64),
                 ("dx_ref", C.c_void_p), ("dx_ref_bs", C.c_int64),
-                ("dx_mask", C.c_int32), ("_pad1", C.c_int32),
+                ("dx_mask", C.c_int32), ("schedule", C.c_int32),
                 ("dw", C.c_void_p), ("y_act", C.c_int32), ("y2_act", C.c_int32), ("y2", C.c_void_p), ("y2_bs", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
@@ -55,7 +58,8 @@ class AdamArgs(C.Structure):
 
 class StftArgs(C.Structure):
     _fields_ = [("n_signals", C.c_int32), ("n_samples", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32),
-                ("n_frames", C.c_int32), ("polar", C.c_int32), ("y", C.c_void_p), ("out", C.c_void_p)]
+                ("n_frames", C.c_int32), ("polar", C.c_int32), ("single_frame", C.c_int32), ("_pad0", C.c_int32),
+                ("y", C.c_void_p), ("out", C.c_void_p)]
 
 
 class PolarArgs(C.Structure):
@@ -65,7 +69,7 @@ class PolarArgs(C.Structure):
 
 class IstftArgs(C.Structure):
     _fields_ = [("n_signals", C.c_int32), ("bins", C.c_int32), ("n_frames", C.c_int32), ("hop", C.c_int32),
-                ("mode", C.c_int32), ("normalize", C.c_int32),
+                ("mode", C.c_int32), ("normalize", C.c_int32), ("single_frame", C.c_int32), ("_pad0", C.c_int32),
                 ("a", C.c_void_p), ("a_bs", C.c_int64), ("b", C.c_void_p), ("b_bs", C.c_int64),
                 ("audio", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
@@ -88,17 +92,14 @@ SYMBOLS = {
     "pg_convt1d_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pg_convt1d_dgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pg_convt1d_wgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "pg_conv_describe": (C.c_int, [C.POINTER(ConvArgs), C.c_int32, C.c_char_p, C.c_int32]),
     "pg_workspace_bytes_conv": (C.c_int64, []),
-    "pg_conv_set_schedule": (C.c_int, [C.c_int]),
-    "pg_conv_set_precision": (C.c_int, [C.c_int32]),
-    "pg_conv_set_oversubscribe": (C.c_int, [C.c_int]),
     "pg_bn_fwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),
     "pg_bn_bwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),
     "pg_workspace_bytes_loss": (C.c_int64, [C.POINTER(LossArgs)]),
     "pg_loss_fwd_bwd": (C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     "pg_adam_step": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p]),
     "pg_stft": (C.c_int, [C.POINTER(StftArgs), C.c_void_p]),
-    "pg_stft_set_mode": (C.c_int, [C.c_int32]),
     "pg_stft_frame_index": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pg_polar": (C.c_int, [C.POINTER(PolarArgs), C.c_void_p]),
     "pg_workspace_bytes_istft": (C.c_int64, [C.POINTER(IstftArgs)]),
@@ -128,13 +129,6 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
-    # PHASEGEN_CONV_PRECISION=fp32|bf16|bf16x3 selects the MFMA operand mode at load (pg_conv_set_precision; default fp32)
-    mode = os.environ.get("PHASEGEN_CONV_PRECISION")
-    if mode:
-        modes = {"fp32": 0, "bf16": 1, "bf16x3": 2}
-        if mode not in modes:
-            raise RuntimeError(f"PHASEGEN_CONV_PRECISION={mode!r}: expected one of {sorted(modes)}")
-        check(lib.pg_conv_set_precision(modes[mode]), "conv_set_precision")
     return lib
 
 

@@ -96,7 +96,7 @@ def griffin_lim(spec, n_fft, hop_length, n_iter, init=None, seed=None):
     for _ in range(n_iter):
         ops.stft(recon[None], n_fft, hop_length, out=S)
         ops.gl_project(S[0], mag, x[0], new_spec)
-        ops.conv_fwd(x, W, fr, 1, 0)
+        ops.conv_fwd(x, W, fr, 1, 0, precision="fp32", schedule=0)   # the inverse DFT is always exact-fp32 MFMA
         prev.copy_(recon)
         ops.ola_nt(fr[0], hop_length, recon)
     if n_iter > 0:

@@ -5,7 +5,10 @@ signature and yield format -- ``[x, label]`` with x (b, 2, bins, frames) float32
 every epoch, short last batch kept -- but the whole dataset lives in HBM (288 GB per MI355X) after ONE upload, so a
 training step does no host->device copy at all (the reference uploads the batch four times per step,
 train.py:42,49,50,57; ``.cuda()`` on what this loader yields is a no-op, so the reference loop runs unchanged).
-For data-parallel training rank r of W takes clips r::W of each epoch's permutation (same seed on every rank).
+For data-parallel training rank r of W takes clips r::W of each epoch's permutation (same seed on every rank), after the
+permutation has been cut to a whole number of GLOBAL batches (W x batch_size clips): every rank then yields the same number
+of full batches per epoch, so the ranks issue the same number of gradient all-reduces (a rank that ran one step more than
+its peers would pair its collectives with the next epoch's and hang or silently diverge).
 """
 import os
 
@@ -47,8 +50,19 @@ class SpectrogramLoader:
         self._gen = torch.Generator(device="cpu")
         self._gen.manual_seed(torch.initial_seed() if seed is None else seed)
 
+    def _usable(self):
+        """Clips of an epoch that are dealt out: all of them on one GPU (the short last batch is yielded and dropped by the
+        caller, train.py:38-39); with W ranks a whole number of global batches, so that every rank steps equally often."""
+        n = self.data.shape[0]
+        if self.world == 1:
+            return n
+        g = self.world * self.batch_size
+        if n < g:
+            raise ValueError(f"data-parallel loader: {n} clips do not fill one global batch of {self.world} x {self.batch_size}")
+        return n // g * g
+
     def __len__(self):
-        n = len(range(self.rank, self.data.shape[0], self.world))
+        n = len(range(self.rank, self._usable(), self.world))
         return (n + self.batch_size - 1) // self.batch_size
 
     def num_clips(self):
@@ -57,7 +71,7 @@ class SpectrogramLoader:
     def __iter__(self):
         n = self.data.shape[0]
         perm = torch.randperm(n, generator=self._gen) if self.shuffle else torch.arange(n)
-        perm = perm[self.rank::self.world].to(self.data.device)
+        perm = perm[:self._usable()][self.rank::self.world].to(self.data.device)
         for s0 in range(0, perm.numel(), self.batch_size):
             idx = perm[s0:s0 + self.batch_size]
             yield [self.data.index_select(0, idx), self.labels.index_select(0, idx)]

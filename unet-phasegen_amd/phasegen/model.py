@@ -11,16 +11,30 @@ from .unet import UNetEngine
 
 
 class _UNetFn(torch.autograd.Function):
-    """Whole-network autograd node: lets the reference's ``loss.backward(); optim.step()`` loop run unchanged."""
+    """Whole-network autograd node: lets the reference's ``loss.backward(); optim.step()`` loop run unchanged.
+
+    The engine keeps ONE set of activations (the last forward's) and ONE gradient arena that backward overwrites, so two
+    things the general autograd contract allows are refused loudly instead of giving silently wrong gradients: backward of
+    an output that is not the engine's most recent forward, and gradient accumulation (backward while ``p.grad`` still
+    holds the previous gradients -- the reference calls ``optim.zero_grad()`` every step, train.py:41)."""
 
     @staticmethod
     def forward(ctx, engine, x, *params):
         ctx.engine = engine
-        return engine.forward(x.detach()).clone()
+        ctx.params = params
+        out = engine.forward(x.detach()).clone()
+        ctx.fwd_id = engine.fwd_count
+        return out
 
     @staticmethod
     def backward(ctx, g):
         eng = ctx.engine
+        if eng.fwd_count != ctx.fwd_id:
+            raise RuntimeError("phasegen UNetModel: backward through a forward that is no longer the engine's latest "
+                               "(run no-grad forwards, e.g. validation, under torch.no_grad() AFTER loss.backward())")
+        if any(p.grad is not None for p in ctx.params):
+            raise RuntimeError("phasegen UNetModel: gradient accumulation is not supported -- call optim.zero_grad() "
+                               "before loss.backward() (the gradient arena is overwritten by every backward)")
         eng.backward(g)
         return (None, None) + tuple(eng.arena.g(k) for k in detgen.param_order())
 
@@ -80,7 +94,9 @@ class _CpuView:
 
 
 class UNetModel(nn.Module):
-    def __init__(self, input_nc, output_nc, norm_layer=nn.BatchNorm2d, gpu_ids=[]):
+    def __init__(self, input_nc, output_nc, norm_layer=nn.BatchNorm2d, gpu_ids=[], precision=None):
+        """Reference signature (model.py:23) + ``precision``: MFMA operand mode of this model's convolutions
+        ("fp32" = the reference's arithmetic, "bf16x3", "bf16"; None = the calling thread's default, fp32)."""
         super().__init__()
         if output_nc != 2 * input_nc:
             raise NotImplementedError("phasegen UNetModel: output_nc must be 2*input_nc ([phase ; magnitude], train.py:45)")
@@ -88,12 +104,14 @@ class UNetModel(nn.Module):
             raise NotImplementedError("phasegen UNetModel: only BatchNorm (the reference's configuration) is implemented")
         self.gpu_ids = list(gpu_ids)
         dev = torch.device("cuda", self.gpu_ids[0]) if self.gpu_ids else None
-        self.engine = UNetEngine(input_nc, dev)
+        self.engine = UNetEngine(input_nc, dev, precision=precision)
         self.engine.arena.init_default()
         self.model = _StateHolder(self.engine.arena)
 
     # nn.parallel.data_parallel (model.py:40-41) is replaced by one process per GPU + RCCL (phasegen.trainer)
     def forward(self, input):
+        if torch.is_tensor(input) and input.is_cuda and input.device != self.engine.device:
+            input = input.to(self.engine.device)      # the reference moves its input to the model's GPU (.cuda(gpu_id))
         if torch.is_grad_enabled():
             params = [self.model.param(k) for k in detgen.param_order()]
             return _UNetFn.apply(self.engine, input, *params)

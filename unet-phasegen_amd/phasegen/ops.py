@@ -5,7 +5,9 @@ kernel behind ``include/phasegen.h``.  Activation tensors are (B, channels, fram
 and channel stride is ``frames``; the batch stride is free, so the two halves of a U-Net concat buffer are passed
 as plain slices ``buf[:, :n]`` / ``buf[:, n:]`` without a copy.
 """
+import contextlib
 import ctypes as C
+import threading
 
 import torch
 
@@ -17,11 +19,21 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_current_device(t, name):
+    """Kernels are launched on the CURRENT device's current stream: a tensor that lives on another GPU would make the
+    kernel dereference foreign pointers (a GPU memory fault that aborts the process) -- raise instead."""
+    if t.device.index != torch.cuda.current_device():
+        raise ValueError(f"{name}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
+                         "(wrap the call in torch.cuda.device(...))")
+
+
 class KernelTimer:
-    """HIP-event timing of labelled launches on the stream they are launched on (bench.py's roofline leg)."""
+    """HIP-event timing of labelled launches on the stream they are launched on (bench.py's roofline leg), plus each
+    label's launch plan (pg_conv_describe: the kernel symbol rocprofv3 will report for it)."""
 
     def __init__(self):
         self.records = {}
+        self.plans = {}
 
     def summary(self):
         torch.cuda.synchronize()
@@ -29,6 +41,7 @@ class KernelTimer:
 
 
 _timer = None
+_cur_label = None
 
 
 def set_timer(t):
@@ -36,20 +49,36 @@ def set_timer(t):
     _timer = t
 
 
+def conv_describe(a, op):
+    """pg_conv_describe: 'kernel<...>|grid=G|tiles=T|slabs=S|split=0/1' for a filled ConvArgs (nothing is launched)."""
+    buf = C.create_string_buffer(256)
+    _lib.check(_lib.load().pg_conv_describe(C.byref(a), op, buf, 256), "conv_describe")
+    return buf.value.decode()
+
+
+def _note_plan(a, op):
+    if _timer is not None and _cur_label is not None and _cur_label not in _timer.plans:
+        _timer.plans[_cur_label] = conv_describe(a, op)
+
+
 class timed:
     def __init__(self, label):
         self.label = label
 
     def __enter__(self):
+        global _cur_label
         if _timer is not None:
+            _cur_label = self.label
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record()
 
     def __exit__(self, *exc):
+        global _cur_label
         if _timer is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             _timer.records.setdefault(self.label, []).append((self.a, b))
+            _cur_label = None
 
 
 def _act3(t, name):
@@ -58,6 +87,7 @@ def _act3(t, name):
         return None, 0
     if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3):
         raise ValueError(f"{name}: expected a 3-D float32 device tensor, got {tuple(t.shape)} {t.dtype} {t.device}")
+    _on_current_device(t, name)
     B, Cc, L = t.shape
     if t.stride(2) != 1 or (Cc > 1 and t.stride(1) != L):
         raise ValueError(f"{name}: frames must be contiguous and channel stride == frames (strides {t.stride()})")
@@ -67,6 +97,7 @@ def _act3(t, name):
 def _dense(t, name):
     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise ValueError(f"{name}: expected a contiguous float32 device tensor")
+    _on_current_device(t, name)
     return t.data_ptr()
 
 
@@ -81,39 +112,89 @@ def convt_out_len(Lin, k, s, p):
 _conv_ws = {}
 
 
+def _ws_key(device):
+    """Workspaces are owned by one stream at a time: key the caches by (device, current stream)."""
+    device = torch.device(device)
+    return (device, torch.cuda.current_stream(device).cuda_stream)
+
+
 def conv_workspace(device):
-    """One scratch buffer per device for the conv kernels' stream-K schedule (pg_workspace_bytes_conv(), 128 MiB)."""
-    ws = _conv_ws.get(device)
+    """Scratch for the conv kernels' stream-K schedule (pg_workspace_bytes_conv(), 128 MiB), one per (device, STREAM):
+    launches on one stream are ordered and may share it, launches on different streams may overlap and must not."""
+    key = _ws_key(device)
+    ws = _conv_ws.get(key)
     if ws is None:
-        ws = _conv_ws[device] = torch.empty(_lib.load().pg_workspace_bytes_conv(), device=device, dtype=torch.uint8)
+        ws = _conv_ws[key] = torch.empty(_lib.load().pg_workspace_bytes_conv(), device=device, dtype=torch.uint8)
     return ws
 
 
-def set_conv_schedule(mode):
-    """Test hook.  Bits 0-1: 0 automatic, 1 one tile per workgroup, 2 force the stream-K split; bit 2 (value 4):
-    disable the raw-window F/T kernels (use the im2col kernels); bit 3 (value 8): never pick the tall 256 x 128 raw tile."""
-    _lib.check(_lib.load().pg_conv_set_schedule(mode), "conv_set_schedule")
+# ---- per-call knobs ---------------------------------------------------------------------------------------------
+# The C ABI keeps no state: MFMA operand precision and work-split schedule are fields of pg_conv_args, the FFT schedule
+# a field of pg_stft_args / pg_istft_args.  Every op below takes them as keyword arguments; when omitted, the calling
+# THREAD's defaults apply (a fresh thread starts at fp32 / automatic), so two threads can drive two streams in different
+# precisions.  The engine passes its own precision explicitly.
+_PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, 0: 0, 1: 1, 2: 2}
 
 
-def set_conv_oversubscribe(factor):
-    """Stream-K grid = factor x resident workgroup slots.  Use > 1 when other kernels (RCCL collectives) share the chip."""
-    _lib.check(_lib.load().pg_conv_set_oversubscribe(factor), "conv_set_oversubscribe")
+class _Defaults(threading.local):
+    precision = 0
+    schedule = 0
+    stft_single = 0
+
+
+_tls = _Defaults()
+
+
+def precision_code(mode):
+    if mode not in _PRECISIONS:
+        raise ValueError(f"conv precision {mode!r}: expected fp32 / bf16 / bf16x3 (or 0 / 1 / 2)")
+    return _PRECISIONS[mode]
 
 
 def set_conv_precision(mode):
-    """0 / "fp32": fp32 MFMA operands (the parity path, default).  1 / "bf16": operands rounded to bf16 at fragment
-    load, fp32 accumulate, fp32 tensors and master weights (BASELINE config 5)."""
-    mode = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2}.get(mode, mode)
-    _lib.check(_lib.load().pg_conv_set_precision(int(mode)), "conv_set_precision")
+    """This thread's default MFMA operand mode.  0 / "fp32": fp32 operands (the parity path).  1 / "bf16": operands rounded
+    to bf16 at fragment load, fp32 accumulate, fp32 tensors and master weights (BASELINE config 5).  2 / "bf16x3": split."""
+    _tls.precision = precision_code(mode)
+
+
+def set_conv_schedule(mode):
+    """This thread's default schedule bits (test hook).  Bits 0-1: 0 automatic, 1 one tile per workgroup, 2 force the stream-K
+    split; bit 2 (value 4): im2col kernels instead of the raw-window ones; bit 3 (value 8): never the tall 256 x 128 raw tile."""
+    if mode < 0 or mode > 15 or (mode & 3) == 3:
+        raise ValueError("conv schedule: bad mode")
+    _tls.schedule = (_tls.schedule & ~0xf) | mode
+
+
+def set_conv_oversubscribe(factor):
+    """Stream-K grid = factor x resident workgroup slots (1..8).  Use > 1 when other kernels (RCCL collectives) share the chip."""
+    if not 1 <= factor <= 8:
+        raise ValueError("conv oversubscribe: factor must be 1..8")
+    _tls.schedule = (_tls.schedule & 0xf) | (factor << 8)
 
 
 def set_stft_mode(single_frame):
     """0: 4 frames per workgroup through the half-length radix-4 real FFT (default); 1: one frame per workgroup, radix-2."""
-    _lib.check(_lib.load().pg_stft_set_mode(int(bool(single_frame))), "stft_set_mode")
+    _tls.stft_single = int(bool(single_frame))
 
 
-def _conv_args(transposed, B, Cin, Cout, Lin, k, s, p, device=None):
+@contextlib.contextmanager
+def conv_options(precision=None, schedule=None):
+    """Scoped thread defaults: ``with ops.conv_options(precision="bf16"): ...``."""
+    old = (_tls.precision, _tls.schedule)
+    if precision is not None:
+        _tls.precision = precision_code(precision)
+    if schedule is not None:
+        _tls.schedule = schedule
+    try:
+        yield
+    finally:
+        _tls.precision, _tls.schedule = old
+
+
+def _conv_args(transposed, B, Cin, Cout, Lin, k, s, p, device=None, precision=None, schedule=None):
     a = _lib.ConvArgs()
+    a.precision = _tls.precision if precision is None else precision_code(precision)
+    a.schedule = _tls.schedule if schedule is None else schedule
     a.B, a.Cin, a.Cout, a.Lin, a.k, a.stride, a.pad = B, Cin, Cout, Lin, k, s, p
     a.Lout = convt_out_len(Lin, k, s, p) if transposed else conv_out_len(Lin, k, s, p)
     if device is not None:
@@ -130,12 +211,13 @@ def _geom(transposed, w, k=None):
     return Cin, Cout, kk
 
 
-def conv_fwd(x, w, y, stride, pad, x_act=ACT_NONE, transposed=False, y_act=ACT_NONE, y2=None, y2_act=ACT_NONE):
+def conv_fwd(x, w, y, stride, pad, x_act=ACT_NONE, transposed=False, y_act=ACT_NONE, y2=None, y2_act=ACT_NONE,
+             precision=None, schedule=None):
     """y = y_act(conv(x_act(x), w)) (nn.Conv1d, model.py:77) or conv_transpose (model.py:88) -- writes into ``y``;
     optionally a second copy ``y2 = y2_act(conv(...))`` (pre-activated tensors for the consumers)."""
     Cin, Cout, k = _geom(transposed, w)
     B, _, Lin = x.shape
-    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, x.device)
+    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, x.device, precision, schedule)
     if tuple(x.shape) != (B, Cin, Lin) or tuple(y.shape) != (B, Cout, a.Lout):
         raise ValueError(f"conv_fwd: shapes x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)} inconsistent (Lout {a.Lout})")
     a.x, a.x_bs = _act3(x, "x")
@@ -147,16 +229,17 @@ def conv_fwd(x, w, y, stride, pad, x_act=ACT_NONE, transposed=False, y_act=ACT_N
             raise ValueError("conv_fwd: y2 must have y's shape")
         a.y2, a.y2_bs = _act3(y2, "y2")
     lib = _lib.load()
+    _note_plan(a, _lib.OP_CONVT1D_FWD if transposed else _lib.OP_CONV1D_FWD)
     fn = lib.pg_convt1d_fwd if transposed else lib.pg_conv1d_fwd
     _lib.check(fn(C.byref(a), _stream()), "convt1d_fwd" if transposed else "conv1d_fwd")
     return y
 
 
-def conv_dgrad(dy, w, dx, stride, pad, transposed=False, add=None, ref=None, mask=ACT_NONE):
+def conv_dgrad(dy, w, dx, stride, pad, transposed=False, add=None, ref=None, mask=ACT_NONE, precision=None, schedule=None):
     """dx = dgrad(dy, w) [+ add] [* act'(ref)] -- grad wrt the tensor the forward op read."""
     Cin, Cout, k = _geom(transposed, w)
     B, _, Lin = dx.shape
-    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, dx.device)
+    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, dx.device, precision, schedule)
     if tuple(dy.shape) != (B, Cout, a.Lout) or tuple(dx.shape) != (B, Cin, Lin):
         raise ValueError(f"conv_dgrad: shapes dy{tuple(dy.shape)} w{tuple(w.shape)} dx{tuple(dx.shape)} inconsistent")
     a.dy, a.dy_bs = _act3(dy, "dy")
@@ -172,16 +255,17 @@ def conv_dgrad(dy, w, dx, stride, pad, transposed=False, add=None, ref=None, mas
         a.dx_ref, a.dx_ref_bs = _act3(ref, "ref")
         a.dx_mask = mask
     lib = _lib.load()
+    _note_plan(a, _lib.OP_CONVT1D_DGRAD if transposed else _lib.OP_CONV1D_DGRAD)
     fn = lib.pg_convt1d_dgrad if transposed else lib.pg_conv1d_dgrad
     _lib.check(fn(C.byref(a), _stream()), "dgrad")
     return dx
 
 
-def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False):
+def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False, precision=None, schedule=None):
     """dw = wgrad(act(x), dy), overwriting ``dw`` (same layout as the weight)."""
     Cin, Cout, k = _geom(transposed, dw)
     B, _, Lin = x.shape
-    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, x.device)
+    a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, x.device, precision, schedule)
     if tuple(x.shape) != (B, Cin, Lin) or tuple(dy.shape) != (B, Cout, a.Lout):
         raise ValueError(f"conv_wgrad: shapes x{tuple(x.shape)} dy{tuple(dy.shape)} dw{tuple(dw.shape)} inconsistent")
     a.x, a.x_bs = _act3(x, "x")
@@ -189,6 +273,7 @@ def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False):
     a.dw = _dense(dw, "dw")
     a.x_act = x_act
     lib = _lib.load()
+    _note_plan(a, _lib.OP_CONVT1D_WGRAD if transposed else _lib.OP_CONV1D_WGRAD)
     fn = lib.pg_convt1d_wgrad if transposed else lib.pg_conv1d_wgrad
     _lib.check(fn(C.byref(a), _stream()), "wgrad")
     return dw
@@ -244,10 +329,10 @@ def loss_fwd_bwd(pred, batch, dpred=None, losses=None, mag_weight=0.2):
     a.losses = _dense(losses, "losses")
     lib = _lib.load()
     need = lib.pg_workspace_bytes_loss(C.byref(a))
-    ws = _loss_ws.get(pred.device)
+    ws = _loss_ws.get(_ws_key(pred.device))
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty((need + 3) // 4, device=pred.device, dtype=torch.float32)
-        _loss_ws[pred.device] = ws
+        _loss_ws[_ws_key(pred.device)] = ws
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _lib.check(lib.pg_loss_fwd_bwd(C.byref(a), _stream()), "loss_fwd_bwd")
     return losses
@@ -266,7 +351,7 @@ def fill(t, value):
     return t
 
 
-def stft(y, n_fft, hop, polar=False, out=None):
+def stft(y, n_fft, hop, polar=False, out=None, single_frame=None):
     """(n_signals, n_samples) -> (n_signals, 2, n_fft/2, 1 + n_samples // hop); preproc_mdb.py:84-97 (+ data.py:39-47)."""
     if y.dim() == 1:
         y = y[None]
@@ -276,6 +361,7 @@ def stft(y, n_fft, hop, polar=False, out=None):
         out = torch.empty(n_sig, 2, n_fft // 2, nf, device=y.device, dtype=torch.float32)
     a = _lib.StftArgs()
     a.n_signals, a.n_samples, a.n_fft, a.hop, a.n_frames, a.polar = n_sig, n_samp, n_fft, hop, nf, int(polar)
+    a.single_frame = _tls.stft_single if single_frame is None else int(bool(single_frame))
     a.y, a.out = _dense(y, "y"), _dense(out, "out")
     _lib.check(_lib.load().pg_stft(C.byref(a), _stream()), "stft")
     return out
@@ -303,7 +389,7 @@ def polar(d, out=None, use_exp=True):
 _istft_ws = {}
 
 
-def istft(a_t, b_t, hop, mode=0, normalize=True):
+def istft(a_t, b_t, hop, mode=0, normalize=True, single_frame=None):
     """(n, bins, frames) x2 -> (n, hop*(frames-1)).  mode 0: (logmag, phase) per demo.py:39; mode 1: (re, im).
     utils.py:34-42: zero DC row, librosa.istft, peak normalisation."""
     n, bins, nf = a_t.shape
@@ -313,14 +399,15 @@ def istft(a_t, b_t, hop, mode=0, normalize=True):
         s1 = min(n, s0 + 64)
         a = _lib.IstftArgs()
         a.n_signals, a.bins, a.n_frames, a.hop, a.mode, a.normalize = s1 - s0, bins, nf, hop, mode, int(normalize)
+        a.single_frame = _tls.stft_single if single_frame is None else int(bool(single_frame))
         a.a, a.a_bs = _act3(a_t[s0:s1], "a")
         a.b, a.b_bs = _act3(b_t[s0:s1], "b")
         a.audio = audio[s0:s1].data_ptr()
         need = lib.pg_workspace_bytes_istft(C.byref(a))
-        ws = _istft_ws.get(a_t.device)
+        ws = _istft_ws.get(_ws_key(a_t.device))
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, device=a_t.device, dtype=torch.uint8)
-            _istft_ws[a_t.device] = ws
+            _istft_ws[_ws_key(a_t.device)] = ws
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(lib.pg_istft(C.byref(a), _stream()), "istft")
     return audio
@@ -345,9 +432,9 @@ def ola_nt(frames_nt, hop, audio, normalize=False):
     a.n_fft, a.frames = frames_nt.shape
     a.hop, a.normalize = hop, int(normalize)
     a.fr, a.audio = _dense(frames_nt, "frames"), _dense(audio, "audio")
-    ws = _ola_ws.get(audio.device)
+    ws = _ola_ws.get(_ws_key(audio.device))
     if ws is None:
-        ws = _ola_ws[audio.device] = torch.empty(256, device=audio.device, dtype=torch.uint8)
+        ws = _ola_ws[_ws_key(audio.device)] = torch.empty(256, device=audio.device, dtype=torch.uint8)
     a.workspace, a.workspace_bytes = ws.data_ptr(), 256
     _lib.check(_lib.load().pg_ola_nt(C.byref(a), _stream()), "ola_nt")
     return audio

@@ -59,12 +59,13 @@ class BucketedAllReduce:
         self._wire = {}              #         the sum runs in bf16 inside the collective, the arena keeps fp32
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.always = always and dist.is_available() and dist.is_initialized()   # run the collective even at world 1 (tests)
+        self.enabled = True          # False: launch() only records the order (bench.py's compute-only diagnostic step)
         self.pending = []
         self.launched = []
 
     def launch(self, name):
         self.launched.append(name)
-        if not (self.world > 1 or self.always):
+        if not self.enabled or not (self.world > 1 or self.always):
             return
         g = self.buckets.view(name)
         if self.compress is None:
@@ -87,11 +88,17 @@ class BucketedAllReduce:
 
 
 class Trainer:
+    """``loss_fn(pred, batch, dpred, losses, mag_weight)`` and ``optim`` default to the device kernels (pg_loss_fwd_bwd,
+    fused Adam).  They are injection points for tests/test_dp_gloo.py, which drives THIS step's control flow (bucket launches
+    from inside backward, wait_all, grad_scale = 1/world) on CPU ranks with an oracle-backed engine; the product never
+    passes them."""
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, mag_weight=0.2, always_reduce=False,
-                 grad_compress=None):
+                 grad_compress=None, loss_fn=None, optim=None):
         self.model = model
         self.engine = model.engine
-        self.optim = Adam(model.parameters(), lr=lr, betas=betas, eps=eps)
+        self.optim = optim if optim is not None else Adam(model.parameters(), lr=lr, betas=betas, eps=eps)
+        self._loss = loss_fn if loss_fn is not None else ops.loss_fwd_bwd
         self.reducer = BucketedAllReduce(self.engine.arena, group, always=always_reduce, compress=grad_compress)
         self.world = self.reducer.world
         self.mag_weight = mag_weight
@@ -104,7 +111,7 @@ class Trainer:
         dpred = self._dpred.get(pred.shape)
         if dpred is None:
             dpred = self._dpred[pred.shape] = torch.empty_like(pred)
-        ops.loss_fwd_bwd(pred, batch, dpred, self.losses, self.mag_weight)
+        self._loss(pred, batch, dpred, self.losses, self.mag_weight)
         self.engine.backward(dpred, self.reducer.launch)
         self.reducer.wait_all()
         self.optim.step(grad_scale=1.0 / self.world)

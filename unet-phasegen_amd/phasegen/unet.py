@@ -119,11 +119,16 @@ class ParamArena:
 class UNetEngine:
     """Forward / backward of the whole network through libphasegen, with a per-(B, L) activation plan."""
 
-    def __init__(self, C, device=None):
+    def __init__(self, C, device=None, precision=None):
         if not torch.cuda.is_available():
             raise RuntimeError("phasegen.UNetEngine needs an MI355X (no CPU fallback exists for the hot path)")
         self.C = C
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        # MFMA operand mode of every conv of this engine (pg_conv_args.precision); None = the calling thread's default
+        self.precision = None if precision is None else ops.precision_code(precision)
+        self.fwd_count = 0           # forward passes so far: backward() refers to the LAST one (checked by the autograd node)
         self.arena = ParamArena(C, self.device)
         self.plans = {}
         self.bn_save = {k: (torch.empty(2 * C, device=self.device), torch.empty(2 * C, device=self.device))
@@ -165,7 +170,8 @@ class UNetEngine:
     def _conv(self, name, x, y, y_act=ACT_NONE, y2=None, y2_act=ACT_NONE):
         key, kind, s, p = LAYERS[name]
         with ops.timed(name + ".fwd"):
-            ops.conv_fwd(x, self.arena.p(key), y, s, p, transposed=(kind == "t"), y_act=y_act, y2=y2, y2_act=y2_act)
+            ops.conv_fwd(x, self.arena.p(key), y, s, p, transposed=(kind == "t"), y_act=y_act, y2=y2, y2_act=y2_act,
+                         precision=self.precision)
 
     def _bn(self, name, x, y, update_stats, y_act=ACT_NONE, y2=None, y2_act=ACT_NONE):
         key = BN_OF[name]
@@ -185,6 +191,12 @@ class UNetEngine:
             raise ValueError(f"UNet: expected input (B, {self.C}, L), got {tuple(x.shape)}")
         if not x.is_cuda or x.dtype != torch.float32:
             raise ValueError("UNet: input must be a float32 device tensor")
+        if x.device != self.device:
+            raise ValueError(f"UNet: input is on {x.device}, the engine on {self.device}")
+        with torch.cuda.device(self.device):     # kernels launch on the CURRENT device's stream: make that the engine's
+            return self._forward(x, update_stats)
+
+    def _forward(self, x, update_stats):
         B, C, L = x.shape           # batch-strided views (e.g. batch[:, 0] of a (B,2,C,L) batch) are read in place
         plan = self.plan(B, L)
         f = plan["fwd"]
@@ -203,6 +215,7 @@ class UNetEngine:
         self._bn("U1", f["r1"], f["cat0"][:, h:], update_stats, ACT_RELU)
         self._conv("U0", f["cat0"], f["r0"])
         self._bn("U0", f["r0"], f["out"], update_stats)
+        self.fwd_count += 1
         self.cur = (plan, x)
         return f["out"]
 
@@ -213,6 +226,10 @@ class UNetEngine:
         have been enqueued -- the data-parallel wrapper launches that bucket's all-reduce from it."""
         if self.cur is None:
             raise RuntimeError("UNet.backward called before forward")
+        with torch.cuda.device(self.device):
+            self._backward(g_out, on_grads_ready)
+
+    def _backward(self, g_out, on_grads_ready):
         plan, x0 = self.cur
         f = plan["fwd"]
         B = x0.shape[0]
@@ -229,12 +246,12 @@ class UNetEngine:
         def wgrad(name, x, dy, act):
             key, kind, s, p = LAYERS[name]
             with ops.timed(name + ".wgrad"):
-                ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"))
+                ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"), precision=self.precision)
 
         def dgrad(name, dy, dx, **kw):
             key, kind, s, p = LAYERS[name]
             with ops.timed(name + ".dgrad"):
-                ops.conv_dgrad(dy, a.p(key), dx, s, p, transposed=(kind == "t"), **kw)
+                ops.conv_dgrad(dy, a.p(key), dx, s, p, transposed=(kind == "t"), precision=self.precision, **kw)
 
         def ready(name):
             if on_grads_ready is not None:

@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--frames", type=int, default=128, help="frames per synthetic clip")
     ap.add_argument("--grad_compress", choices=["none", "bf16"], default="none", help="payload of the data-parallel gradient all-reduce")
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
-                    help="MFMA operand mode of the convolutions (pg_conv_set_precision): fp32 = the reference's arithmetic")
+                    help="MFMA operand mode of the convolutions (pg_conv_args.precision): fp32 = the reference's arithmetic")
     a = ap.parse_args()
 
     import numpy as np
@@ -52,8 +52,6 @@ def main():
     import torch.distributed as dist
     from phasegen import detgen
     from phasegen.data import SpectrogramLoader, get_fft_npy_loader
-    from phasegen import ops as _ops
-    _ops.set_conv_precision(a.precision)
     from phasegen.model import UNetModel
     from phasegen.trainer import Trainer
     from phasegen.validate import validation_metrics
@@ -64,7 +62,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", gpu_id))
     torch.manual_seed(0)                                                      # same init and same permutations on every rank
-    model = UNetModel(a.channels, a.channels * 2, gpu_ids=[gpu_id]).cuda(gpu_id)
+    model = UNetModel(a.channels, a.channels * 2, gpu_ids=[gpu_id], precision=a.precision).cuda(gpu_id)
     if a.synthetic:
         d = torch.from_numpy(detgen.make_batch(a.synthetic, a.channels, a.frames, seed=1)).cuda()
         loader = SpectrogramLoader(d, torch.zeros(a.synthetic, 1, device=d.device), a.batch_size, True, rank, world, seed=0)
