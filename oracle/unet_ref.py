@@ -68,42 +68,79 @@ def batch_norm_train(x, gamma, beta, stats=None, prefix=None):
     return y
 
 
-def unet_forward(p, x, stats=None, capture=None):
+def unet_forward(p, x, stats=None, capture=None, masks=None):
     """(B, C, L) -> (B, 2C, L).  ``p``: dict of torch tensors keyed like the reference state-dict.
 
     ``capture`` (optional dict) receives every intermediate named as in DESIGN.md:
       a0, c1, h1, c2, h2, d3, r3, u3, r2, u2, r1, u1, r0, out
+
+    ``masks`` (optional dict of bool tensors keyed a0, h1, h2, d3, u3, u2, u1; test aid for full-width GRADIENT parity):
+    every (Leaky)ReLU is evaluated with the given sign pattern instead of the tensor's own -- LeakyReLU(t) = t * where(m, 1,
+    0.2), ReLU(t) = t * m.  With the masks of the run under test the function is the same network wherever the two runs agree
+    on signs (everywhere except pre-activations within rounding of zero, where t itself is ~0), but its gradient no longer
+    jumps when a pre-activation that is zero to rounding lands on the other side: a flipped mask otherwise changes whole rows
+    of the weight gradients by O(1/sqrt(B L')) and makes end-to-end gradient comparison at 1e-4 meaningless.
     """
     cap = capture if capture is not None else {}
 
     def bn(t, key):
         return batch_norm_train(t, p[key + ".weight"], p[key + ".bias"], stats, key)
 
+    if masks is not None:
+        class F:                                                  # noqa: N801  (shadows torch.nn.functional below on purpose)
+            conv1d = staticmethod(torch.nn.functional.conv1d)
+            conv_transpose1d = staticmethod(torch.nn.functional.conv_transpose1d)
+            _m = None
+
+            @staticmethod
+            def leaky_relu(t, slope):
+                m = F._m
+                return t * torch.where(m, torch.ones((), dtype=t.dtype), torch.full((), slope, dtype=t.dtype))
+
+            @staticmethod
+            def relu(t):
+                return t * F._m.to(t.dtype)
+
+        def site(*names):                                         # the sign pattern for the next activation call
+            F._m = torch.cat([masks[n] for n in names], 1) if len(names) > 1 else masks[names[0]]
+    else:
+        F = torch.nn.functional
+
+        def site(*names):
+            pass
+
     # outermost down: Conv1d(C -> 2C, k32, s2, p16), no activation in front     model.py:33,90
     a0 = F.conv1d(x, p[K_D0], stride=2, padding=16)
     # block b3: LeakyReLU (in place => skip carries it), Conv1d k8 s1 p2, BN        model.py:31,103
+    site("a0")
     a0l = F.leaky_relu(a0, SLOPE)
     c1 = F.conv1d(a0l, p[K_D1], stride=1, padding=2)
     h1 = bn(c1, BN_D1)
     # block b2: LeakyReLU, Conv1d k8 s2 p1, BN                                       model.py:29,103
+    site("h1")
     h1l = F.leaky_relu(h1, SLOPE)
     c2 = F.conv1d(h1l, p[K_D2], stride=2, padding=1)
     h2 = bn(c2, BN_D2)
     # block b1 (innermost): LeakyReLU, Conv1d k4 s2 p1, ReLU, ConvT k5 s2 p1, BN     model.py:27,96-97
+    site("h2")
     h2l = F.leaky_relu(h2, SLOPE)
     d3 = F.conv1d(h2l, p[K_D3], stride=2, padding=1)
+    site("d3")
     r3 = F.conv_transpose1d(F.relu(d3), p[K_U3], stride=2, padding=1)
     u3 = bn(r3, BN_U3)
     cat2 = torch.cat([h2l, u3], 1)                                                   # model.py:113
     # b2 up: ReLU, ConvT(4C -> 2C, k8, s2, p1), BN                                   model.py:101-104
+    site("h2", "u3")
     r2 = F.conv_transpose1d(F.relu(cat2), p[K_U2], stride=2, padding=1)
     u2 = bn(r2, BN_U2)
     cat1 = torch.cat([h1l, u2], 1)
     # b3 up: ReLU, ConvT(4C -> 2C, k8, s1, p2), BN
+    site("h1", "u2")
     r1 = F.conv_transpose1d(F.relu(cat1), p[K_U1], stride=1, padding=2)
     u1 = bn(r1, BN_U1)
     cat0 = torch.cat([a0l, u1], 1)
     # outermost up: ReLU, ConvT(4C -> 2C, k32, s2, p16), BN; no output non-linearity  model.py:88-92
+    site("a0", "u1")
     r0 = F.conv_transpose1d(F.relu(cat0), p[K_U0], stride=2, padding=16)
     out = bn(r0, BN_U0)
     cap.update(a0=a0, c1=c1, h1=h1, c2=c2, h2=h2, d3=d3, r3=r3, u3=u3, r2=r2, u2=u2, r1=r1, u1=u1,
@@ -136,14 +173,15 @@ def adam_step(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
-def train_step(p, batch, opt_state, stats=None, lr=1e-3):
+def train_step(p, batch, opt_state, stats=None, lr=1e-3, masks=None):
     """One full step of train.py:41-62 on CPU.  ``p`` holds leaf tensors (requires_grad for the 20
-    parameters).  ``opt_state`` = {"step": int, "m": {k: t}, "v": {k: t}}.  Returns (loss, ang, mag, grads)."""
+    parameters).  ``opt_state`` = {"step": int, "m": {k: t}, "v": {k: t}}.  Returns (loss, ang, mag, grads).
+    ``masks``: see unet_forward (full-width gradient parity tests only)."""
     names = [k for k in p if p[k].dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))]
     for k in names:
         p[k].requires_grad_(True)
         p[k].grad = None
-    out = unet_forward(p, batch[:, 0], stats)
+    out = unet_forward(p, batch[:, 0], stats, masks=masks)
     loss, ang, mag = phase_loss(out, batch)
     loss.backward()
     grads = {k: p[k].grad.detach().clone() for k in names}

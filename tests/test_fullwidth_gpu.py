@@ -10,9 +10,18 @@ box's host cores and everything the step produces is compared:
   * C = 1024, L = 256, B = 32 forward only (BASELINE configs[1]) -- the whole output tensor and all 14 intermediates
 
 Tolerances (relative to each tensor's max-abs, fp32 on both sides; measured values in DESIGN.md §5a): loss 1e-5, forward
-tensors 1e-4 (BASELINE.json: "within 1e-4 rel fp32"), gradients 2e-4, Adam exp_avg 2e-4, exp_avg_sq 4e-4 (g squared),
+tensors 1e-4 (BASELINE.json: "within 1e-4 rel fp32"), gradients 1e-4, Adam exp_avg 1e-4, exp_avg_sq 2e-4 (g squared),
 BatchNorm running statistics 1e-4, updated parameters compared where |g| is far above Adam's eps (the first step is
 -lr * g / (|g| + eps)).
+
+Gradients and (Leaky)ReLU masks.  The forward tensors of the two runs agree to ~4e-6, so a handful of the 10^7
+pre-activations that are zero to rounding land on different sides of zero in the two runs.  The network's gradient is
+discontinuous there: one flipped ReLU mask at the bottleneck (60 values per channel at B = 2) moves a whole row of that
+layer's weight gradient by O(1/sqrt(60)) and everything upstream of it by percents (measured: 9e-2 of max-abs in D2's
+weight gradient with 5 disagreeing signs out of 2.8 million) -- that is a property of the function, not of either implementation.  The gradient
+comparison therefore runs the oracle with the DEVICE's sign patterns (oracle/unet_ref.unet_forward(masks=...): the same
+function wherever the runs agree on signs, and a pre-activation whose sign differs is itself ~1e-6), and the test also
+counts the disagreeing signs and checks they are rare and tiny.
 """
 import numpy as np
 import pytest
@@ -54,14 +63,25 @@ def test_train_step_full_width_vs_oracle(C, L, B):
 
     pp, ost, stats = oracle_state(pn)
     cap = {}
-    with torch.no_grad():                                       # forward intermediates (separate no-grad pass: cheap)
+    with torch.no_grad():                                       # the oracle's own forward (its own signs): forward parity
         unet_ref.unet_forward({k: v for k, v in pp.items()}, batch[:, 0], capture=cap)
-    lo, ao, mo, grads = unet_ref.train_step(pp, batch, ost, stats)
+    inter = eng.intermediates()
+    h = 2 * C
+    stored = {"a0": inter["leaky:a0"], "h1": inter["leaky:h1"], "h2": inter["leaky:h2"], "d3": inter["relu:d3"],
+              "u3": inter["relu:u3"], "u2": inter["relu:u2"], "u1": inter["relu:u1"]}
+    masks = {k: (v > 0).cpu() for k, v in stored.items()}      # sign of the stored activated tensors == sign of the pre-activation
+    flips, flipped_mag = 0, 0.0
+    for k, m in masks.items():
+        d = m != (cap[k] > 0)
+        flips += int(d.sum())
+        if d.any():
+            flipped_mag = max(flipped_mag, float(cap[k][d].abs().max() / cap[k].abs().max()))
+    n_act = sum(m.numel() for m in masks.values())
+    lo, ao, mo, grads = unet_ref.train_step(pp, batch, ost, stats, masks=masks)
 
     err = {}
     want = np.array([lo.item(), ao.item(), mo.item()])
     err["loss"] = float(np.max(np.abs(losses - want) / np.abs(want)))
-    inter = eng.intermediates()
     err["out"] = relmax(inter["out"], cap["out"])
     for k in ("c1", "c2", "r3", "r2", "r1", "r0"):              # raw conv outputs at every level
         err["act/" + k] = relmax(inter[k], cap[k])
@@ -79,8 +99,10 @@ def test_train_step_full_width_vs_oracle(C, L, B):
         err["rv/" + k] = relmax(eng.arena.buffers[k + ".running_var"], stats[k + ".running_var"])
         assert int(eng.arena.buffers[k + ".num_batches_tracked"]) == int(stats[k + ".num_batches_tracked"]) == 1
     worst = {g: max((v, k) for k, v in err.items() if k.startswith(g)) for g in ("loss", "out", "act/", "grad/", "m/", "v/", "dp/", "rm/", "rv/")}
-    print(f"\nfull-width parity C={C} L={L} B={B}: " + ", ".join(f"{g}{v[0]:.2e}" for g, v in worst.items()))
-    tol = {"loss": 1e-5, "out": 1e-4, "act/": 1e-4, "grad/": 2e-4, "m/": 2e-4, "v/": 4e-4, "dp/": 2e-2, "rm/": 1e-4, "rv/": 1e-4}
+    print(f"\nfull-width parity C={C} L={L} B={B}: " + ", ".join(f"{g}{v[0]:.2e}" for g, v in worst.items())
+          + f"; sign disagreements with the oracle's own forward: {flips} of {n_act} (largest |pre-activation| among them {flipped_mag:.1e} of max)")
+    assert flips <= 1e-5 * n_act and flipped_mag < 1e-4
+    tol = {"loss": 1e-5, "out": 1e-4, "act/": 1e-4, "grad/": 1e-4, "m/": 1e-4, "v/": 2e-4, "dp/": 2e-2, "rm/": 1e-4, "rv/": 1e-4}
     bad = {k: v for k, v in err.items() if v > next(t for g, t in tol.items() if k.startswith(g))}
     assert not bad, (bad, worst)
 
