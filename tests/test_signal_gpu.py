@@ -201,12 +201,13 @@ def test_griffin_lim_vs_oracle(n_fft, hop, frames, n_iter):
     got_a, got_s, got_l = audio.griffin_lim(mag, n_fft, hop, n_iter, init=init)
     assert got_a.shape == want_a.shape == (n,) and got_s.shape == want_s.shape
     # Tolerance: each iteration is stft -> angle -> istft; the device's inverse is an fp32 GEMM against a 2046-point synthesis
-    # matrix rounded to fp32 (the oracle works in float64), and angle() of small bins amplifies ~1e-6 errors: they compound over
-    # the iterations.  Measured 1e-4 .. 6e-4 for these cases (2-4 iterations); STFT and ISTFT alone hold 2e-5 (tests above).
+    # matrix rounded to fp32 (the oracle works in float64), and angle() of small bins amplifies ~1e-6 errors, which compound over
+    # the iterations.  Measured on MI355X: audio 2e-6 .. 7e-6, spectrum 4e-6 .. 3.4e-5 for these cases; bound 2e-4 (round 1
+    # allowed 2e-3).
     ea, es = relmax(got_a, want_a), float(np.max(np.abs(got_s - want_s)) / np.max(np.abs(want_s)))
     print(f"\ngriffin_lim n_fft={n_fft} iters={n_iter}: audio {ea:.1e} spec {es:.1e} loss {abs(got_l - want_l) / abs(want_l):.1e}")
-    assert ea < 2e-3 and es < 2e-3
-    assert abs(got_l - want_l) < 2e-3 * abs(want_l)
+    assert ea < 2e-4 and es < 2e-4
+    assert abs(got_l - want_l) < 1e-5 * abs(want_l)
     assert abs(np.max(np.abs(got_a)) - 1.0) < 1e-6
     a2, _, _ = audio.griffin_lim(mag, n_fft, hop, n_iter, seed=7)      # seeded random start: reproducible
     a3, _, _ = audio.griffin_lim(mag, n_fft, hop, n_iter, seed=7)

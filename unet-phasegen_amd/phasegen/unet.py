@@ -97,7 +97,9 @@ class ParamArena:
         """torch's default init (model.py builds stock nn.Conv1d / nn.ConvTranspose1d / BatchNorm; weights_init
         at model.py:12-20 is never called): conv weights U(+-1/sqrt(fan_in)), gamma 1, beta 0."""
         gen = torch.Generator(device=self.device)
-        gen.manual_seed(torch.initial_seed() if seed is None else seed)
+        if seed is None:            # drawn FROM torch's global stream, as nn.Module init is: same manual_seed -> same weights, and a
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # second model built afterwards gets different ones
+        gen.manual_seed(seed)
         for k, shp in self.shapes.items():
             v = self.view(k)
             if len(shp) == 3:
@@ -193,6 +195,8 @@ class UNetEngine:
             raise ValueError("UNet: input must be a float32 device tensor")
         if x.device != self.device:
             raise ValueError(f"UNet: input is on {x.device}, the engine on {self.device}")
+        if x.stride(2) != 1 or (x.shape[1] > 1 and x.stride(1) != x.shape[2]):
+            x = x.contiguous()                   # any other layout than (batch-strided) rows of contiguous frames: one copy
         with torch.cuda.device(self.device):     # kernels launch on the CURRENT device's stream: make that the engine's
             return self._forward(x, update_stats)
 

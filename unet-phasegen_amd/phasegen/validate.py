@@ -14,6 +14,7 @@ from . import audio
 @torch.no_grad()
 def validation_metrics(model, val_batch, hop_length=512, n_fft=2048, gl_iters=250, gl_seed=0):
     """val_batch: (n, 2, bins, frames) = [logmag; angle] on the device.  Returns {"MSE", "NOPMSE", "LMSE"} floats."""
+    val_batch = val_batch.contiguous()
     n, _, bins, _ = val_batch.shape
     mses, nops, lims = [], [], []
     for c in range(n):
