@@ -402,7 +402,10 @@ __device__ __forceinline__ void divmod24(int n, int d, float inv, int& q, int& r
 // raw-window tile geometry (kernels in conv_raw.hip / conv_raw_wgrad.hip; the host needs it to size grids and windows)
 constexpr int RBM = 128, RBN = 256;       // raw-window workgroup tile
 constexpr int RS2 = 768, RS1 = 384;       // floats reserved per channel window for column stride 2 / 1
-constexpr int RG = 16;                    // gap between the windows of consecutive samples inside a tile
+// gap (floats) between the windows of consecutive samples inside a tile: a column's taps must never reach into the next
+// sample's window, which needs >= TJ - 1 floats (TJ = taps per channel and slab); short-tap kernels take the small gap so that
+// tiles spanning many short samples (U = 31 columns per sample at the U-Net's bottleneck) still fit their window slots
+constexpr int raw_gap(int tj) { return tj >= 8 ? 16 : tj; }
 constexpr int RTILE_A = RBM * BK;         // weight tile, same swizzled image as above (8 KB)
 
 enum Kind { KIND_F, KIND_T, KIND_G };

@@ -129,7 +129,7 @@ bool raw_supported(Kind kind, const IgemmParams& p, const Knobs& kn, int tn = RB
         if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
         kwp = p.k; sc = p.s; lcol = p.Ly;
     } else if (kind == KIND_T) {
-        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2))) return false;
+        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
         kwp = p.k / p.s; sc = 1; lcol = p.U;
     } else {
         // a 16-element slab of (b, i) may run over at most ONE sample boundary in the raw-window wgrad kernel
@@ -137,17 +137,18 @@ bool raw_supported(Kind kind, const IgemmParams& p, const Knobs& kn, int tn = RB
     }
     const int tj = kwp < 16 ? kwp : 16;
     const int nseg_max = (lcol - 1 + tn - 1) / lcol + 1;
-    return sc * (tn - 1) + tj + RG * (nseg_max - 1) + (kind == KIND_T ? tj : 0) <= (sc == 1 ? RS1 : RS2);
+    return sc * (tn - 1) + tj + raw_gap(tj) * (nseg_max - 1) + (kind == KIND_T ? tj : 0) <= (sc == 1 ? RS1 : RS2);
 }
 
 int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, long Ktot, long ws_bytes, hipStream_t st) {
     bool raw = raw_supported(kind, p, kn);
-    // F / T problems whose columns the tall 256 x 128 tile covers with at least 3 % fewer computed ones take it: small-batch
+    // F / T problems whose columns the tall 256 x 128 tile covers with at least 3 % fewer computed ones take it (and those whose
+    // windows only fit the narrower tile: many short samples per tile): small-batch
     // inference above all (a 128 x 256 tile over 65 columns is 3/4 idle MFMA work per weight byte), and training shapes such as
     // N = 16 x 65 (5 wide tiles = 1280 columns vs 9 tall = 1152: +15 % measured) or 64 x 30.  On ties the wide tile wins (it
     // runs two slabs per barrier; measured 1-7 % faster at equal column counts).
     const long cols_wide = (cols + RBN - 1) / RBN * RBN, cols_tall = (cols + RBN / 2 - 1) / (RBN / 2) * (RBN / 2);
-    const bool tall = kind != KIND_G && kn.no_raw == 0 && kn.no_tall == 0 && cols_tall * 100 <= cols_wide * 97 &&
+    const bool tall = kind != KIND_G && kn.no_raw == 0 && kn.no_tall == 0 && (cols_tall * 100 <= cols_wide * 97 || !raw) &&
                       raw_supported(kind, p, kn, RBN / 2);
     if (tall) raw = true;
     const int bm = tall ? 2 * RBM : (raw ? RBM : BM), bn = tall ? RBN / 2 : (raw ? RBN : BN);

@@ -98,13 +98,14 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
     constexpr int TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ;
     constexpr int SC = TKIND ? 1 : S;                 // window positions per column step
+    constexpr int RG = raw_gap(TJ);                   // gap between the windows of consecutive samples
     constexpr int RS = SC == 1 ? RS1 : RS2;           // floats reserved per channel window
     constexpr int NPC = (RS + NT - 1) / NT;           // gather pieces per thread and window
     constexpr int STG = TA + NQ * RS;                 // floats per LDS stage
     // slabs per barrier: two when both stages still fit 64 KB -- except the k = 32 T kernel (U0 forward), which measures 2 %
     // faster with one (146 vs 143 TFLOP/s); the F form and the k = 8 kernels gain 1-5 % from two
     constexpr int SPB = (4 * STG * 4 <= 64 * 1024 && !(TKIND && KW == 32)) ? 2 : 1;
-    static_assert(KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "raw-window kernels need 4/8/16/32 taps per channel");
+    static_assert(KWP == 2 || KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "raw-window kernels need 2/4/8/16/32 taps per channel");
     static_assert(!TKIND || KW % S == 0, "T raw kernel needs s | k");
     __shared__ __attribute__((aligned(16))) float lds[2 * SPB * STG];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -342,6 +343,7 @@ hipError_t launch_raw_ft_wn(int kind, const IgemmParams& p, int grid, hipStream_
         return launch_raw<4, 2, false, WN>(p, grid, st, prec);
     }
     if (p.k == 32) return launch_raw<32, 2, true, WN>(p, grid, st, prec);
+    if (p.k == 4) return launch_raw<4, 2, true, WN>(p, grid, st, prec);
     if (p.s == 1) return launch_raw<8, 1, true, WN>(p, grid, st, prec);
     return launch_raw<8, 2, true, WN>(p, grid, st, prec);
 }
