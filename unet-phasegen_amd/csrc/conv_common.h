@@ -354,6 +354,37 @@ __device__ __forceinline__ void epilogue_t(const IgemmParams& p, const AccT<MB, 
     }
 }
 
+// T epilogue for the stride-2 kernels with the phase-major weight image (conv_raw_impl.h): row block i holds phase phi0 + i
+// of the 32 output channels obase + (row inside the block); columns nbase + j * 32 + lane.
+template <int MB, int NB>
+__device__ __forceinline__ void epilogue_t_pm(const IgemmParams& p, const AccT<MB, NB>& acc, int obase, int nbase, int lane, int phi0) {
+    const int Ntot = p.B * p.U;
+    const Epi ep(p, (unsigned)((long)p.M * p.Ly * 4));
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = nbase + j * 32 + (lane & 31);
+        if (n >= Ntot) continue;
+        const int b = n / p.U, u = n - b * p.U + p.u_off;
+        float* yb = p.y + (long)b * p.y_bs;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int tau = 2 * u + phi0 + i - p.p;
+            if (tau < 0 || tau >= p.Ly) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = obase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (o < p.M) {
+                    const int off = o * p.Ly + tau;
+                    float v = acc.c[i][j][r];
+                    if (ep.fused) v = ep(v, b * (int)p.add_bs + off, b * (int)p.ref_bs + off);
+                    yb[off] = act_apply(v, p.y_slope);
+                    if (p.y2) p.y2[(long)b * p.y2_bs + off] = act_apply(v, p.y2_slope);
+                }
+            }
+        }
+    }
+}
+
 template <int S, int MB, int NB>
 __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const AccT<MB, NB>& acc, int m0, int n0, int lane, int wm, int wn) {
     const int Ntot = p.Q * p.k;

@@ -65,6 +65,8 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
     const int m0 = (tile / p.tilesN) * ((4 / WN) * 32 * MB) + wm * (MB - 1) * 32 + bi * 32;
     const int n0 = (tile % p.tilesN) * (WN * 32 * NB) + wn * (NB - 1) * 32 + bj * 32;
     if (KIND == 0) epilogue_f<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
+    else if (KIND == 3)       // stride-2 raw T kernels (phase-major rows): block row bi is phase bi of the wave's 32 output channels
+        epilogue_t_pm<1, 1>(p, acc, (tile / p.tilesN) * ((4 / WN) * 16 * MB) + wm * 32, (tile % p.tilesN) * (WN * 32 * NB) + wn * (NB * 32) + bj * 32, lane, bi);
     else if (KIND == 1) epilogue_t<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
     else epilogue_g<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
 }
@@ -175,9 +177,11 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     if (e == hipSuccess && grid != tiles) {
         if (tall) {
             if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+            else if (p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
             else hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
         } else if (raw) {
             if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+            else if (kind == KIND_T && p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
             else if (kind == KIND_T) hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
             else hipLaunchKernelGGL((conv_fixup_kernel<2, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
         } else switch (kind) {

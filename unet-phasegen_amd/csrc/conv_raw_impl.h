@@ -22,15 +22,32 @@ namespace {
 // (channel qi, tap tau) = divmod(8h + i, TJ); the element lives at  qi*RS + bbase[jb] +/- tau.
 struct RawFrags { f32x4 a[2][2]; float b[4][8]; };
 
-template <int TJ, bool DESC, int RS>
+template <int TJ, bool DESC, int RS, bool PM>
 __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
                                                const int (&bbase)[4], float slopeA, float slopeB, RawFrags& f) {
-    const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
-    const float* ap = As + (wm * 64 + r) * BK;
+    const int r = lane & 31, h = lane >> 5;
+    if (PM) {
+        // phase-major weight image (stride-2 T kernels): row o = 32 floats = the slab's 16 k x 2 phases exactly as they lie in
+        // memory (W[q][o][2 jj + phi], phases interleaved), 16-byte chunks XOR-swizzled by (o >> 1) & 7.  The lane's 16 floats
+        // [16 h, 16 h + 16) de-interleave in registers: even elements are the phase-0 row's fragment, odd ones the phase-1 row's,
+        // so the wave's two row blocks are (o, phi = 0) and (o, phi = 1) of the same 32 output channels.
+        const int sw = (r >> 1) & 7;
+        const float* ap = As + (wm * 32 + r) * 32;
+        f32x4 v[4];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+        for (int cc = 0; cc < 4; ++cc) v[cc] = *reinterpret_cast<const f32x4*>(ap + (((4 * h + cc) ^ sw) << 2));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) f.a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int phi = 0; phi < 2; ++phi) f.a[phi][kk >> 2][kk & 3] = v[(2 * kk + phi) >> 2][(2 * kk + phi) & 3];
+    } else {
+        const int sw = (r >> 2) & 3;
+        const float* ap = As + (wm * 64 + r) * BK;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) f.a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+    }
     // lane part of the index: TJ == 16 -> one channel, taps 8h + i;  TJ <= 8 -> channels (8/TJ)*h + i/TJ, taps i % TJ
     const int lanepart = (TJ == 16) ? (DESC ? -8 * h : 8 * h) : (8 / TJ) * h * RS;
 #pragma unroll
@@ -77,11 +94,11 @@ __device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
                 acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk >> 2][kk & 3], f.b[j][kk], acc.c[i][j], 0, 0, 0);
 }
 
-template <int TJ, bool DESC, int RS, int BF>
+template <int TJ, bool DESC, int RS, int BF, bool PM>
 __device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
                                              const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
     RawFrags f;
-    raw_load_frags<TJ, DESC, RS>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
+    raw_load_frags<TJ, DESC, RS, PM>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
     raw_mfma<BF>(f, acc);
 }
 
@@ -99,6 +116,8 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     constexpr int TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ;
     constexpr int SC = TKIND ? 1 : S;                 // window positions per column step
     constexpr int RG = raw_gap(TJ);                   // gap between the windows of consecutive samples
+    constexpr bool PM = TKIND && S == 2;              // phase-major weight image, loaded as 16-byte pieces (raw_load_frags)
+    static_assert(!TKIND || S == 1 || (S == 2 && KWP <= 16), "T kernels: stride 1, or stride 2 with at most 16 taps per phase");
     constexpr int RS = SC == 1 ? RS1 : RS2;           // floats reserved per channel window
     constexpr int NPC = (RS + NT - 1) / NT;           // gather pieces per thread and window
     constexpr int STG = TA + NQ * RS;                 // floats per LDS stage
@@ -119,6 +138,11 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
     const float slopeA = 1.0f, slopeB = act_slope(p.act_x);
     const int wq = p.M * KW;                          // T: weight stride between input channels
+    // phase-major image: the LOGICAL 16-byte chunk this lane carries into LDS (physical chunk lane & 7 of a row, XOR the row's
+    // swizzle -- which depends on the wave and lane only, not on the gather instruction) = floats [f, f + 4) of the row's 32:
+    // channel ql of the slab, taps `within ..` of W[q][o][:]
+    const int pm_f = ((lane & 7) ^ (((wv & 1) << 2) | (lane >> 4))) << 2;
+    const int pm_ql = pm_f / (2 * TJ), pm_within = pm_f - pm_ql * 2 * TJ;
     const int g = xcd_remap(blockIdx.x, gridDim.x);
     const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);
     int pos = split_lo(sp, g);
@@ -134,11 +158,19 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
 
         // --- weight-tile gather constants (BYTE offsets) --------------------------------------------------------
         int aoff[AE4], avoff[AE16];
-        if (TKIND) {
+        if (TKIND) {        // stride 1: 16-byte pieces of the tap-contiguous rows (T16 below); stride 2: phase-major image
+            if (PM) {
 #pragma unroll
-            for (int e = 0; e < AE4; ++e) {
-                const int mr = m0 + dma_row(lane, wv, e), o = mr / S, phi = mr - o * S;
-                aoff[e] = mr < Mrows ? (o * KW + phi) * 4 : FAR;              // W[q][o][S*jj + phi]
+                for (int e = 0; e < AE16; ++e) {
+                    const int o = m0 / 2 + (4 * e + wv) * 8 + (lane >> 3);    // row (output channel) of this lane's 16-byte chunk
+                    avoff[e] = o < p.M ? (pm_ql * wq + o * KW + pm_within) * 4 : FAR;   // W[q0 + ql][o][within ..]; q0 rides in the SGPR
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < AE4; ++e) {
+                    const int mr = m0 + dma_row(lane, wv, e);
+                    aoff[e] = mr < Mrows ? mr * KW * 4 : FAR;                 // W[q][o][jj]  (general path of the stride-1 kernels)
+                }
             }
         } else {
 #pragma unroll
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         constexpr int NT0 = (!TKIND && KWP == 32) ? 2 : 1;
         //   T weights at stride 1: the taps of a channel are contiguous in memory AND in K, so the tile loads as 16-byte pieces
         constexpr bool T16 = TKIND && S == 1;
-        int aoffk[(FAST && TKIND && !T16) ? AE4 : 1], avoffk[(FAST && T16) ? AE16 : 1], voffb[FAST ? NT0 : 1][FAST ? NPC : 1];
+        int avoffk[(FAST && T16) ? AE16 : 1], voffb[FAST ? NT0 : 1][FAST ? NPC : 1];
         if (FAST) {
             if (T16) {
                 const int kc = dma16_kc(lane);
@@ -187,10 +219,6 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
                     const int o = m0 + dma16_row(lane, wv, e);
                     avoffk[e] = o < Mrows ? ((kc / KWP) * wq + o * KW + (kc % KWP)) * 4 : FAR;
                 }
-            } else if (TKIND) {
-                const int lk = ((kt / KWP) * wq + S * (kt % KWP)) * 4;
-#pragma unroll
-                for (int e = 0; e < AE4; ++e) aoffk[e] = aoff[e] == FAR ? FAR : aoff[e] + lk;
             }
 #pragma unroll
             for (int h = 0; h < NT0; ++h)
@@ -224,9 +252,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             if (T16) {                                                                                    \
                 const int sa = (k0 / KWP) * wq * 4;                                                       \
                 _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoffk[T16 ? e : 0], sa); \
-            } else if (TKIND) {                                                                           \
+            } else if (PM) {     /* stride-2 T: the phase-major rows as 16-byte pieces */                    \
                 const int sa = (k0 / KWP) * wq * 4;                                                       \
-                _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4s(rw, As + e * 256, aoffk[(TKIND && !T16) ? e : 0], sa); \
+                _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], sa); \
             } else {     /* F: 16-byte pieces always (they only need dword alignment); no branch on a_vec here */ \
                 _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], k0 * 4); \
             }                                                                                             \
@@ -248,18 +276,14 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
                 }                                                                                         \
             }                                                                                             \
         } else {                                                                                          \
-        if (TKIND) {                                                                                      \
+        if (PM) {            /* K tail: channels past Q (and slabs past K) read zeros */                         \
+            const int qa = k0 / KWP;                                                                      \
+            const int sa = (kok && qa + pm_ql < p.Q) ? qa * wq * 4 : OOB;                                 \
+            _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16(rw, As + wv * 192 + e * 1024, avoff[e] + sa); \
+        } else if (TKIND) {                                                                               \
             const int kk = k0 + kt, q = kk / KWP, jj = kk - q * KWP;                                      \
             const int wo = kok ? (q * wq + S * jj) * 4 : OOB;                                             \
-            if (FAST && !T16) {      /* the general offsets are the fast ones minus their per-lane K part (keeps aoff[] dead) */ \
-                const int lk_ = ((kt / KWP) * wq + S * (kt % KWP)) * 4;                                   \
-                _Pragma("unroll") for (int e = 0; e < AE4; ++e) {                                         \
-                    const int ak = aoffk[(FAST && TKIND && !T16) ? e : 0];                                \
-                    dma4(rw, As + e * 256, (ak == FAR ? FAR : ak - lk_) + wo);                            \
-                }                                                                                         \
-            } else {                                                                                      \
-                _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4(rw, As + e * 256, aoff[e] + wo);     \
-            }                                                                                             \
+            _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4(rw, As + e * 256, aoff[e] + wo);         \
         } else if (p.a_vec) {                                                                             \
             const int kv = (k0 + dma16_kc(lane) < Ktot) ? k0 * 4 : OOB;                                   \
             _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16(rw, As + wv * 192 + e * 1024, avoff[e] + kv); \
@@ -299,9 +323,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             for (int hf = 0; hf < SPB; ++hf) RAW_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, (sl + SPB + hf) * BK)
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(1)
-            mma_slab_raw<TJ, TKIND, RS, BF>(lds + cur * SSTG, lds + cur * SSTG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+            mma_slab_raw<TJ, TKIND, RS, BF, PM>(lds + cur * SSTG, lds + cur * SSTG + TA, lane, wm, bbase, slopeA, slopeB, acc);
             if (SPB == 2 && sl + 1 < se)
-                mma_slab_raw<TJ, TKIND, RS, BF>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+                mma_slab_raw<TJ, TKIND, RS, BF, PM>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + TA, lane, wm, bbase, slopeA, slopeB, acc);
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(2)
             __syncthreads();
@@ -310,7 +334,8 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         PG_STAMP_FLUSH
 #undef RAW_ISSUE
         if (sb == 0 && se == p.nslab) {
-            if (TKIND) epilogue_t<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+            if (PM) epilogue_t_pm<2, 4>(p, acc, m0 / 2 + wm * 32, n0 + wn * 128, lane, 0);
+            else if (TKIND) epilogue_t<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
             else epilogue_f<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
         } else store_partial(p.ws, g, slot, acc, tid);
         pos += se - sb;

@@ -58,11 +58,14 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
         // Slabs that lie inside one sample (all but one in LP/16) read the P tile as two 16-byte pieces per thread: 16 consecutive
         // frames of a row are contiguous (16-byte LDS-DMA only needs dword alignment, tools/probe/ldsdma16.hip), the (sample, frame)
         // of the slab is wave-uniform and rides in the SGPR offset.  Enabled where registers allow.
-        constexpr bool FASTP = BF != 2 && (KW == 32 || (KW == 8 && S == 1));
-        int pv[FASTP ? 2 : 1], woff[FASTP ? C::NE : 1];   // (+ window element: channel offset + position inside the window)
-        if (FASTP) {
+        constexpr bool FASTP = BF != 2 && !(KW == 4 && BF != 0);   // (the bf16-mode k = 4 kernels are at the register limit)
+        constexpr bool FASTW = FASTP && KW != 4;          // SGPR-offset window gathers: k = 4 has 9 pieces per thread, their offsets spill
+        int pv[FASTP ? 2 : 1], woff[FASTW ? C::NE : 1];   // (+ window element: channel offset + position inside the window)
+        if (FASTW) {
 #pragma unroll
             for (int e = 0; e < C::NE; ++e) woff[e] = choff[e] == FAR ? FAR : choff[e] + (vv[e] + p.p) * 4;
+        }
+        if (FASTP) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int m = m0 + dma16_row(lane, wv, e);
@@ -100,10 +103,10 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
           const int po = bb < p.B ? bb * pbs4 + ii * 4 : OOB;                                             \
           _Pragma("unroll") for (int e = 0; e < 8; ++e) dma4(rp, As + e * 256, aoff[e] + po); }           \
         const int w0 = S * gi - p.p;                   /* memory position of window element 0 */          \
-        if (FASTP && kc >= 16 && gb < p.B && w0 >= 0 && w0 + C::WLP <= p.Lx) {   /* window inside the row: no per-lane checks */ \
+        if (FASTW && kc >= 16 && gb < p.B && w0 >= 0 && w0 + C::WLP <= p.Lx) {   /* window inside the row: no per-lane checks */ \
             const int sw_ = gb * xbs4 + w0 * 4;                                                           \
             _Pragma("unroll") for (int e = 0; e < C::NE; ++e)                                             \
-                if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) dma4s(rx, Bw + e * NT, woff[FASTP ? e : 0], sw_); \
+                if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) dma4s(rx, Bw + e * NT, woff[FASTW ? e : 0], sw_); \
         } else {                                                                                          \
         const int sb0 = gb < p.B ? gb * xbs4 : -NEVER, sb1 = (kc < 16 && gb + 1 < p.B) ? (gb + 1) * xbs4 : -NEVER; \
         _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                               \
