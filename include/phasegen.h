@@ -123,7 +123,9 @@ int pg_loss_fwd_bwd(const pg_loss_args* a, void* stream);
 typedef struct pg_adam_args {
     int64_t n; float* p; const float* g; float* m; float* v;
     double lr, beta1, beta2, eps, grad_scale;   /* Python floats, rounded to fp32 exactly where torch rounds them */
-    int32_t step; int32_t _pad0;
+    int32_t step;
+    int32_t thin;    /* 0: full-rate streaming launch (the chip is idle); 1: at most one small workgroup per CU, <= 32 VGPRs,  */
+                     /*    non-temporal accesses -- for running BESIDE the MFMA-bound conv kernels of backward on another stream */
 } pg_adam_args;
 int pg_adam_step(const pg_adam_args* a, void* stream);
 

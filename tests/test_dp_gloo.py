@@ -197,7 +197,7 @@ def trainer_worker(rank, port, q):
         for d in loader:
             assert d[0].shape[0] == B_LOADER                 # no short batch on any rank
             losses.append(tr.step(d[0]).clone())
-            assert tr.reducer.pending == [] and model.engine.calls[-8:] == BACKWARD_ORDER
+            assert not tr.reducer.pending and model.engine.calls[-8:] == BACKWARD_ORDER
             steps += 1
         q.put((rank, steps, model.engine.arena.flat.clone().numpy(), torch.stack(losses).numpy()))
         dist.barrier()

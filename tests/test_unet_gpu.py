@@ -216,3 +216,21 @@ def test_optimizer_state_resume_is_exact(tmp_path):
     lr_ = r.step(batches[2])
     assert torch.equal(lr_, la) and torch.equal(r.engine.arena.flat, a.engine.arena.flat)
     assert r.optim.step_count == 3
+
+
+def test_overlapped_adam_is_bit_identical_to_the_serial_update():
+    """Trainer runs each layer's slice of the Adam update on a side stream beside the rest of backward (the update is
+    HBM-bound, backward's convolutions MFMA-bound).  Elementwise arithmetic: three steps must leave parameters, Adam
+    state and losses BIT-identical to the serial schedule (backward, then one update over the whole arena)."""
+    from phasegen.trainer import Trainer
+    C, L, B = 16, 64, 3
+    batches = [torch.from_numpy(detgen.make_batch(B, C, L, seed=40 + i)).cuda() for i in range(3)]
+    a, b = Trainer(make_model(C), overlap_adam=True), Trainer(make_model(C), overlap_adam=False)
+    assert a.overlap_adam and not b.overlap_adam
+    for x in batches:
+        la, lb = a.step(x).clone(), b.step(x).clone()
+        assert torch.equal(la, lb)
+    torch.cuda.synchronize()
+    assert torch.equal(a.engine.arena.flat, b.engine.arena.flat)
+    assert torch.equal(a.optim.m, b.optim.m) and torch.equal(a.optim.v, b.optim.v)
+    assert a.optim.step_count == b.optim.step_count == 3

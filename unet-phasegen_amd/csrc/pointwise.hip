@@ -165,6 +165,32 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// "Thin" variant for running BESIDE the MFMA-bound convolution kernels of backward (pg_adam_args.thin; phasegen.trainer):
+// one 256-thread workgroup per CU at most, <= 32 VGPRs so that its four waves fit into the registers the conv kernels
+// leave free (2 waves x <= 240 of 512 per SIMD), non-temporal loads and stores so that the 28 B per parameter it streams do
+// not evict the conv kernels' operands from L2 / Infinity Cache.  Slower than adam_kernel on an idle chip (fewer bytes in
+// flight), which does not matter in the shadow of ~100 ms of convolutions.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256)
+void adam_thin_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                      float omb1, float b2, float omb2, float step_size, float bc2_sqrt, float eps, float gs) {
+    const long n2 = n >> 1;          // two parameters per thread and iteration: 23 VGPRs (four need 41)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+        f32x2 pp = __builtin_nontemporal_load(reinterpret_cast<f32x2*>(p) + i), gg = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(g) + i);
+        f32x2 mm = __builtin_nontemporal_load(reinterpret_cast<f32x2*>(m) + i), vv = __builtin_nontemporal_load(reinterpret_cast<f32x2*>(v) + i);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float a = pp[k], b = mm[k], c = vv[k];
+            adam_one(a, gg[k], b, c, omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
+            pp[k] = a; mm[k] = b; vv[k] = c;
+        }
+        __builtin_nontemporal_store(pp, reinterpret_cast<f32x2*>(p) + i);
+        __builtin_nontemporal_store(mm, reinterpret_cast<f32x2*>(m) + i);
+        __builtin_nontemporal_store(vv, reinterpret_cast<f32x2*>(v) + i);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) adam_one(p[n - 1], g[n - 1], m[n - 1], v[n - 1], omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // data.py:39-47: [re; im] -> [log1p(|z|); angle(z)], 16 B of traffic per bin-frame.
 // ---------------------------------------------------------------------------------------------------------
@@ -250,6 +276,14 @@ extern "C" int pg_adam_step(const pg_adam_args* a, void* stream) {
     const double bc1 = 1.0 - pow(a->beta1, a->step), bc2 = 1.0 - pow(a->beta2, a->step);
     const float step_size = (float)(a->lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     long blocks = ((a->n >> 2) + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    if (a->thin) {
+        const long cus = pg_cu_count();
+        if (blocks > cus) blocks = cus;
+        hipLaunchKernelGGL(adam_thin_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v, (long)a->n,
+                           (float)(1.0 - a->beta1), (float)a->beta2, (float)(1.0 - a->beta2), step_size, bc2_sqrt, (float)a->eps,
+                           (float)a->grad_scale);
+        return launch_ok("adam launch failed");
+    }
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v, (long)a->n,
                        (float)(1.0 - a->beta1), (float)a->beta2, (float)(1.0 - a->beta2), step_size, bc2_sqrt, (float)a->eps,
                        (float)a->grad_scale);

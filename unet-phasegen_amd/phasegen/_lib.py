@@ -53,7 +53,7 @@ class LossArgs(C.Structure):
 class AdamArgs(C.Structure):
     _fields_ = [("n", C.c_int64), ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("grad_scale", C.c_double), ("step", C.c_int32), ("_pad0", C.c_int32)]
+                ("grad_scale", C.c_double), ("step", C.c_int32), ("thin", C.c_int32)]
 
 
 class StftArgs(C.Structure):

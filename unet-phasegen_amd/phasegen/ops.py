@@ -338,8 +338,9 @@ def loss_fwd_bwd(pred, batch, dpred=None, losses=None, mag_weight=0.2):
     return losses
 
 
-def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+def adam_step(p, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, thin=False):
     a = _lib.AdamArgs()
+    a.thin = int(bool(thin))
     a.n = p.numel()
     a.p, a.g, a.m, a.v = _dense(p, "p"), _dense(g, "g"), _dense(m, "m"), _dense(v, "v")
     a.lr, a.beta1, a.beta2, a.eps, a.grad_scale, a.step = lr, beta1, beta2, eps, grad_scale, step

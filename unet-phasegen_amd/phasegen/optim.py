@@ -50,6 +50,19 @@ class Adam:
                 ops.adam_step(p.data.view(-1), p.grad.contiguous().view(-1), m.view(-1), v.view(-1), self.step_count,
                               lr, b1, b2, self.eps, grad_scale)
 
+    # -- per-layer stepping (phasegen.trainer overlaps these with the rest of backward on a side stream) -------------------
+    def begin_step(self):
+        self.step_count += 1
+
+    @torch.no_grad()
+    def step_range(self, start, end, grad_scale=1.0, thin=False):
+        """The update of arena elements [start, end) for the step begun with begin_step() -- elementwise, so stepping the
+        arena range by range gives bit-identical results to one step() over the whole arena."""
+        a = self.arena
+        b1, b2 = self.betas
+        ops.adam_step(a.flat[start:end], a.grad[start:end], self.m[start:end], self.v[start:end], self.step_count,
+                      self.param_groups[0]["lr"], b1, b2, self.eps, grad_scale, thin=thin)
+
     def state_dict(self):
         return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.param_groups[0]["lr"]}
 

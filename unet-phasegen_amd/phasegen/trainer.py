@@ -60,7 +60,7 @@ class BucketedAllReduce:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.always = always and dist.is_available() and dist.is_initialized()   # run the collective even at world 1 (tests)
         self.enabled = True          # False: launch() only records the order (bench.py's compute-only diagnostic step)
-        self.pending = []
+        self.pending = {}            # bucket name -> (work, wire, fp32 view), in launch order
         self.launched = []
 
     def launch(self, name):
@@ -69,20 +69,26 @@ class BucketedAllReduce:
             return
         g = self.buckets.view(name)
         if self.compress is None:
-            self.pending.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+            self.pending[name] = (dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None)
             return
         wire = self._wire.get(name)
         if wire is None:
             wire = self._wire[name] = torch.empty(g.shape, dtype=torch.bfloat16, device=g.device)
         wire.copy_(g)                                                          # fp32 -> bf16 (RNE) on the launch stream
-        self.pending.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True), wire, g))
+        self.pending[name] = (dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True), wire, g)
 
-    def wait_all(self):
-        for w, wire, g in self.pending:
+    def wait(self, name):
+        """Make the CURRENT stream wait for bucket ``name``'s collective (no-op if none is pending for it)."""
+        item = self.pending.pop(name, None)
+        if item is not None:
+            w, wire, g = item
             w.wait()
             if wire is not None:
                 g.copy_(wire)                                                  # bf16 sum -> fp32 arena
-        self.pending.clear()
+
+    def wait_all(self):
+        for name in list(self.pending):
+            self.wait(name)
         done, self.launched = self.launched, []
         return done
 
@@ -94,7 +100,7 @@ class Trainer:
     passes them."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, mag_weight=0.2, always_reduce=False,
-                 grad_compress=None, loss_fn=None, optim=None):
+                 grad_compress=None, loss_fn=None, optim=None, overlap_adam=True):
         self.model = model
         self.engine = model.engine
         self.optim = optim if optim is not None else Adam(model.parameters(), lr=lr, betas=betas, eps=eps)
@@ -104,6 +110,13 @@ class Trainer:
         self.mag_weight = mag_weight
         self.losses = torch.zeros(3, device=self.engine.device)
         self._dpred = {}
+        # Adam is HBM-bound (28 B per parameter, 17 GB per step) while the convolutions of backward are MFMA-bound and leave
+        # HBM almost idle: each layer's slice of the update runs on a SIDE stream as soon as backward no longer reads that
+        # layer's parameters (and, data-parallel, as soon as its gradient bucket's all-reduce has completed), beside the
+        # remaining backward kernels.  Elementwise, so bit-identical to one update over the whole arena after backward.
+        self.overlap_adam = bool(overlap_adam and self.engine.device.type == "cuda" and hasattr(self.optim, "step_range"))
+        self._side = torch.cuda.Stream(self.engine.device) if self.overlap_adam else None
+        self._due = []
 
     def step(self, batch):
         """batch: (B, 2, C, L) = [logmag ; angle] on the device.  Returns the device tensor [loss, ang, mag]."""
@@ -112,11 +125,39 @@ class Trainer:
         if dpred is None:
             dpred = self._dpred[pred.shape] = torch.empty_like(pred)
         self._loss(pred, batch, dpred, self.losses, self.mag_weight)
-        self.engine.backward(dpred, self.reducer.launch)
-        self.reducer.wait_all()
-        self.optim.step(grad_scale=1.0 / self.world)
+        if not self.overlap_adam:
+            self.engine.backward(dpred, self.reducer.launch)
+            self.reducer.wait_all()
+            self.optim.step(grad_scale=1.0 / self.world)
+            return self.losses
+        self.optim.begin_step()
+        self._due.clear()
+        self.engine.backward(dpred, self._grads_ready, self._due.append)
+        self._update_due()                                                       # the last layers: nothing left to hide under
+        torch.cuda.current_stream(self.engine.device).wait_stream(self._side)    # the next forward reads the updated weights
+        self.reducer.wait_all()                                                  # (nothing left pending: bookkeeping only)
         return self.losses
 
+    def _grads_ready(self, name):
+        """Called by backward right after layer ``name``'s wgrad has been enqueued: start its bucket's all-reduce, and start the
+        update of the layers backward is already done with (their last reader, the dgrad, was enqueued earlier) -- HERE, so
+        that the HBM-bound update runs beside the dgrad that follows, not beside a wgrad: measured on MI355X, the wgrad
+        kernels lose as much time to a concurrent Adam as the overlap saves, the dgrad kernels lose none."""
+        self.reducer.launch(name)
+        self._update_due()
+
+    def _update_due(self):
+        if not self._due:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            for name in self._due:
+                s, e = self.reducer.buckets.spans[name]
+                self.reducer.wait(name)                      # data parallel: the bucket's all-reduce (RCCL's stream) is awaited HERE,
+                self.optim.step_range(s, e, 1.0 / self.world)   # on the side stream, not on the stream that runs backward
+        self._due.clear()
 
     # -- checkpoint / resume (SURVEY.md §8f row N3).  The reference saves the model only (model.py:45-48) and cannot
     # resume; the model file keeps that exact format (UNetModel.save) and the optimiser state goes next to it.

@@ -224,16 +224,18 @@ class UNetEngine:
         return f["out"]
 
     # -- backward ----------------------------------------------------------------------------------------------
-    def backward(self, g_out, on_grads_ready=None):
+    def backward(self, g_out, on_grads_ready=None, on_layer_done=None):
         """Gradients of all 20 parameters into the gradient arena (overwritten).  ``on_grads_ready(layer)`` is
         called right after the kernels that complete a layer's gradients (conv weight + its BatchNorm's gamma/beta)
-        have been enqueued -- the data-parallel wrapper launches that bucket's all-reduce from it."""
+        have been enqueued -- the data-parallel wrapper launches that bucket's all-reduce from it.  ``on_layer_done(layer)``
+        is called once backward has enqueued its LAST kernel that reads the layer's parameters (the dgrad): from there on
+        the optimiser may overwrite them while the remaining layers' backward kernels run."""
         if self.cur is None:
             raise RuntimeError("UNet.backward called before forward")
         with torch.cuda.device(self.device):
-            self._backward(g_out, on_grads_ready)
+            self._backward(g_out, on_grads_ready, on_layer_done)
 
-    def _backward(self, g_out, on_grads_ready):
+    def _backward(self, g_out, on_grads_ready, on_layer_done=None):
         plan, x0 = self.cur
         f = plan["fwd"]
         B = x0.shape[0]
@@ -261,6 +263,10 @@ class UNetEngine:
             if on_grads_ready is not None:
                 on_grads_ready(name)
 
+        def done(name):
+            if on_layer_done is not None:
+                on_layer_done(name)
+
         # up path, outermost first.  Operands are the stored activated tensors (identity on load); the mask relu'(.) is
         # taken from their sign.
         for name, cat, raw, gin, g_raw, g_cat in (("U0", "cat0", "r0", g_out, "g_r0", "g_cat0"),
@@ -271,20 +277,25 @@ class UNetEngine:
             wgrad(name, f[cat], g[g_raw], ACT_NONE)
             ready(name)
             dgrad(name, g[g_raw], g[g_cat], ref=f[cat], mask=ACT_RELU)
+            done(name)
         # down path, innermost first; each dgrad adds the skip gradient and applies leaky' (sign of the stored leaky(h))
         wgrad("D3", f["l2"], g["g_d3"], ACT_NONE)
         ready("D3")
         dgrad("D3", g["g_d3"], g["g_cat2"][:, :h], add=g["g_cat2"][:, :h], ref=f["l2"], mask=ACT_LEAKY)
+        done("D3")
         bn_bwd("D2", f["c2"], g["g_cat2"][:, :h], g["g_c2"])
         wgrad("D2", f["l1"], g["g_c2"], ACT_NONE)
         ready("D2")
         dgrad("D2", g["g_c2"], g["g_cat1"][:, :h], add=g["g_cat1"][:, :h], ref=f["l1"], mask=ACT_LEAKY)
+        done("D2")
         bn_bwd("D1", f["c1"], g["g_cat1"][:, :h], g["g_c1"])
         wgrad("D1", f["l0"], g["g_c1"], ACT_NONE)
         ready("D1")
         dgrad("D1", g["g_c1"], g["g_cat0"][:, :h], add=g["g_cat0"][:, :h], ref=f["l0"], mask=ACT_LEAKY)
+        done("D1")
         wgrad("D0", x0, g["g_cat0"][:, :h], ACT_NONE)      # network input needs no dgrad
         ready("D0")
+        done("D0")
 
     def layer_param_keys(self, name):
         keys = [LAYERS[name][0]]
