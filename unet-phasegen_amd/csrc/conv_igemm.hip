@@ -86,15 +86,17 @@ struct Knobs {
     int no_raw;       // 1 = never use the raw-window kernels (exercise the im2col kernels)
     int no_tall;      // 1 = never use the tall 256 x 128 raw tile
     int oversub;      // stream-K grid = up to oversub x resident workgroup slots
+    int contended;    // other kernels (RCCL collectives) are expected to hold part of the chip: always take the finer split
     char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
 };
 int decode_knobs(const pg_conv_args* a, Knobs& k) {
     if (a->precision < 0 || a->precision > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv: precision must be PG_PREC_FP32, PG_PREC_BF16 or PG_PREC_BF16X3");
     const int sc = a->schedule;
-    if (sc < 0 || (sc & ~0xf0f) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
+    if (sc < 0 || (sc & ~0xf1f) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
     k.prec = a->precision;
     k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
     k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
+    k.contended = (sc >> 4) & 1;
     k.desc = nullptr; k.desc_len = 0;
     return PG_OK;
 }
@@ -108,9 +110,17 @@ int cu_count() { return pg_cu_count(); }
 // degrades gracefully when slots are taken (16 of 512 slots held: 1x split 33 -> 58 ms, one-tile-per-workgroup 32 -> 43 ms,
 // 4x split 33 -> 37 ms).  Small problems (less than 8 slabs per resident slot, or no workspace) run one tile per
 // workgroup.  mode: 0 auto, 1 force one tile per workgroup, 2 force stream-K (tests).
-int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mode, int oversub) {
+int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mode, int oversub, int contended) {
     const long total = tiles * (long)nslab;
     const long slots = (long)cu_count() * WG_PER_CU;
+    // A tile count that is a whole multiple of the resident slots quantises perfectly: whole tiles per workgroup, no partial
+    // tiles through the workspace and no fixup launch (measured: the fixups of the five such layers of the U-Net cost 0.5 ms
+    // per step).  Not when the chip is shared (data-parallel backward beside RCCL): there the finer split bounds the tail.
+    if (mode == 0 && !contended && tiles % slots == 0) {
+        if (tiles <= slots * oversub) return (int)tiles;
+        for (long mult = oversub; mult >= 1; --mult)
+            if (tiles % (slots * mult) == 0) return (int)(slots * mult);       // several whole tiles per workgroup
+    }
     long mult = total / (256 * slots);               // whole multiples of the slot count only (a ragged second wave is
     if (mult > oversub) mult = oversub;              // worse than none), and >= 256 slabs per workgroup so that partial-
     if (mult < 1) mult = 1;                          // tile traffic stays negligible
@@ -159,14 +169,16 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     p.nslab = (int)((Ktot + BK - 1) / BK);
     const long tiles = (long)p.tilesM * p.tilesN;
     if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");   // the fixup launches 8 workgroups per tile
-    const int grid = pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub);
+    const int grid = pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended);
+    // ranges made of whole tiles (grid == tiles, or a grid that divides the tile count) leave nothing for the fixup
+    const bool split = grid != tiles && !(tiles % grid == 0);
     if (kn.desc) {      // the kernel this call would launch, named as rocprofv3 names it (profiles/*_kernel_stats.csv)
         const bool spec = (p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || (p.k == 5 && p.s == 2);
         char name[96];
         if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_raw_kernel<%d, %d, %d>", p.k, p.s, kn.prec);
         else if (raw) snprintf(name, sizeof name, "conv_raw_kernel<%d, %d, %s, %d, %d>", p.k, p.s, kind == KIND_T ? "true" : "false", kn.prec, tall ? 1 : 2);
         else snprintf(name, sizeof name, "conv_%c_kernel<%d, %d, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), spec ? p.k : 0, spec ? p.s : 0, kn.prec);
-        snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d", name, grid, tiles, p.nslab, grid != tiles);
+        snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d", name, grid, tiles, p.nslab, (int)split);
         return PG_OK;
     }
     hipError_t e;
@@ -174,7 +186,7 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     else if (tall) e = pgconv::launch_raw_ft_tall(kind, p, grid, st, kn.prec);
     else if (raw) e = pgconv::launch_raw_ft(kind, p, grid, st, kn.prec);
     else e = pgconv::launch_im2col(kind, p, grid, st, kn.prec);
-    if (e == hipSuccess && grid != tiles) {
+    if (e == hipSuccess && split) {
         if (tall) {
             if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
             else if (p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);

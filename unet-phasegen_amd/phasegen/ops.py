@@ -12,7 +12,7 @@ import threading
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU  # noqa: F401  (re-exported)
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, SCHED_CONTENDED  # noqa: F401  (re-exported)
 
 
 def _stream():
@@ -155,6 +155,11 @@ def set_conv_precision(mode):
     """This thread's default MFMA operand mode.  0 / "fp32": fp32 operands (the parity path).  1 / "bf16": operands rounded
     to bf16 at fragment load, fp32 accumulate, fp32 tensors and master weights (BASELINE config 5).  2 / "bf16x3": split."""
     _tls.precision = precision_code(mode)
+
+
+def current_schedule():
+    """This thread's default pg_conv_args.schedule word."""
+    return _tls.schedule
 
 
 def set_conv_schedule(mode):

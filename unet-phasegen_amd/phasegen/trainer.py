@@ -107,6 +107,8 @@ class Trainer:
         self._loss = loss_fn if loss_fn is not None else ops.loss_fwd_bwd
         self.reducer = BucketedAllReduce(self.engine.arena, group, always=always_reduce, compress=grad_compress)
         self.world = self.reducer.world
+        if self.world > 1 and hasattr(self.engine, "contended"):
+            self.engine.contended = True        # RCCL's collective kernels run beside backward's convolutions
         self.mag_weight = mag_weight
         self.losses = torch.zeros(3, device=self.engine.device)
         self._dpred = {}

@@ -130,6 +130,8 @@ class UNetEngine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         # MFMA operand mode of every conv of this engine (pg_conv_args.precision); None = the calling thread's default
         self.precision = None if precision is None else ops.precision_code(precision)
+        self.contended = False       # True (set by the data-parallel Trainer): RCCL's kernels share the chip during backward ->
+        #                              backward convs keep the fine stream-K split (pg_conv_args.schedule, PG_SCHED_CONTENDED)
         self.fwd_count = 0           # forward passes so far: backward() refers to the LAST one (checked by the autograd node)
         self.arena = ParamArena(C, self.device)
         self.plans = {}
@@ -243,6 +245,7 @@ class UNetEngine:
         a = self.arena
         h = 2 * self.C
         g_out = g_out.contiguous()
+        sched = (ops.current_schedule() | ops.SCHED_CONTENDED) if self.contended else None
 
         def bn_bwd(name, raw, dy, dx):
             key = BN_OF[name]
@@ -252,12 +255,12 @@ class UNetEngine:
         def wgrad(name, x, dy, act):
             key, kind, s, p = LAYERS[name]
             with ops.timed(name + ".wgrad"):
-                ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"), precision=self.precision)
+                ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"), precision=self.precision, schedule=sched)
 
         def dgrad(name, dy, dx, **kw):
             key, kind, s, p = LAYERS[name]
             with ops.timed(name + ".dgrad"):
-                ops.conv_dgrad(dy, a.p(key), dx, s, p, transposed=(kind == "t"), precision=self.precision, **kw)
+                ops.conv_dgrad(dy, a.p(key), dx, s, p, transposed=(kind == "t"), precision=self.precision, schedule=sched, **kw)
 
         def ready(name):
             if on_grads_ready is not None:
