@@ -56,6 +56,94 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const pg_bn_args a) {
     }
 }
 
+// Register-resident variants (every shape of the U-Net: frames <= 256, batch <= 64): the channel's B x L values are read from
+// HBM ONCE into registers -- thread t owns frame t % LR of samples t / LR, t / LR + G, ... (LR = frames rounded up to a power
+// of two, G = 256 / LR sample groups: coalesced rows, no integer division) -- and mean, variance and the normalised /
+// activated outputs are all computed from there: 1 read + 1-2 writes instead of 3 reads.  Same two-pass arithmetic
+// (mean first, then the centred squares), block sums in a fixed order.
+template <int EPT>
+__global__ __launch_bounds__(256) void bn_fwd_reg_kernel(const pg_bn_args a, int lr_shift) {
+    __shared__ float scratch[16];
+    const int c = blockIdx.x, n = a.B * a.L;
+    const int l = threadIdx.x & ((1 << lr_shift) - 1), g = threadIdx.x >> lr_shift, G = 256 >> lr_shift;
+    const bool lok = l < a.L;
+    const float* xc = a.x + (long)c * a.L + l;
+    float v[EPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int b = g + i * G;
+        v[i] = (lok && b < a.B) ? xc[(long)b * a.x_bs] : 0.f;
+        s += v[i];
+    }
+    const float mean = pg_block_sum(s, scratch) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const float d = (lok && g + i * G < a.B) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float var = pg_block_sum(q, scratch) / (float)n;
+    const float invstd = 1.0f / sqrtf(var + a.eps);
+    const float ga = a.gamma[c], be = a.beta[c];
+    float* yc = a.y + (long)c * a.L + l;
+    float* y2c = a.y2 ? a.y2 + (long)c * a.L + l : nullptr;
+    const float s1 = bn_slope(a.y_act), s2 = bn_slope(a.y2_act);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int b = g + i * G;
+        if (lok && b < a.B) {
+            const float o = (v[i] - mean) * invstd * ga + be;
+            yc[(long)b * a.y_bs] = fmaxf(o, s1 * o);
+            if (y2c) y2c[(long)b * a.y2_bs] = fmaxf(o, s2 * o);
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.save_mean[c] = mean;
+        a.save_invstd[c] = invstd;
+        if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+        if (a.running_var) {
+            const float unbiased = var * ((float)n / (float)(n > 1 ? n - 1 : 1));
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unbiased;
+        }
+    }
+}
+
+template <int EPT>
+__global__ __launch_bounds__(256) void bn_bwd_reg_kernel(const pg_bn_args a, int lr_shift) {
+    __shared__ float scratch[16];
+    const int c = blockIdx.x, n = a.B * a.L;
+    const int l = threadIdx.x & ((1 << lr_shift) - 1), g = threadIdx.x >> lr_shift, G = 256 >> lr_shift;
+    const bool lok = l < a.L;
+    const float* xc = a.x + (long)c * a.L + l;
+    const float* dyc = a.dy + (long)c * a.L + l;
+    const float mean = a.save_mean[c], invstd = a.save_invstd[c];
+    float xh[EPT], dy[EPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int b = g + i * G;
+        const bool ok = lok && b < a.B;
+        dy[i] = ok ? dyc[(long)b * a.dy_bs] : 0.f;
+        xh[i] = ok ? (xc[(long)b * a.x_bs] - mean) * invstd : 0.f;
+        s1 += dy[i];
+        s2 += dy[i] * xh[i];
+    }
+    const float sum_dy = pg_block_sum(s1, scratch);
+    const float sum_dy_xhat = pg_block_sum(s2, scratch);
+    const float k = a.gamma[c] * invstd, m1 = sum_dy / (float)n, m2 = sum_dy_xhat / (float)n;
+    float* dxc = a.dx + (long)c * a.L + l;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int b = g + i * G;
+        if (lok && b < a.B) dxc[(long)b * a.dx_bs] = k * (dy[i] - m1 - xh[i] * m2);
+    }
+    if (threadIdx.x == 0) {
+        a.dgamma[c] = sum_dy_xhat;
+        a.dbeta[c] = sum_dy;
+    }
+}
+
 // dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat));  dgamma = sum(dy * xhat);  dbeta = sum(dy)
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const pg_bn_args a) {
     __shared__ float scratch[16];
@@ -120,9 +208,12 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const pg_loss_args a,
 }
 
 __global__ __launch_bounds__(64) void loss_final_kernel(const float* partial, int nblocks, double n, float mag_weight, float* losses) {
+    // lane i adds partials i, i + 64, ... in double, then a fixed shuffle tree: deterministic, 64x shorter than one lane alone
+    double c = 0, s = 0, m = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) { c += partial[i * 3]; s += partial[i * 3 + 1]; m += partial[i * 3 + 2]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); s += __shfl_xor(s, off, 64); m += __shfl_xor(m, off, 64); }
     if (threadIdx.x == 0) {
-        double c = 0, s = 0, m = 0;
-        for (int i = 0; i < nblocks; ++i) { c += partial[i * 3]; s += partial[i * 3 + 1]; m += partial[i * 3 + 2]; }
         const float cos_l = (float)(c / n), sin_l = (float)(s / n), mag_l = (float)(m / n);
         const float ang = cos_l + sin_l;
         losses[0] = ang + mag_l * mag_weight; losses[1] = ang; losses[2] = mag_l;
@@ -236,13 +327,27 @@ int bn_check(const pg_bn_args* a) {
     return PG_OK;
 }
 
+// register-resident BN: frames fit one workgroup row (<= 256) and each thread's share of the batch fits 64 registers
+bool bn_reg_plan(const pg_bn_args* a, int& lr_shift, int& ept) {
+    if (a->L > 256) return false;
+    lr_shift = 0;
+    while ((1 << lr_shift) < a->L) ++lr_shift;
+    const int G = 256 >> lr_shift;
+    ept = (a->B + G - 1) / G;
+    return ept <= 64;
+}
+
 }  // namespace
 
 extern "C" int pg_bn_fwd(const pg_bn_args* a, void* stream) {
     if (int e = bn_check(a)) return e;
     if (!a->x || !a->y || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd)
         return pg_fail(PG_ERR_NULL, "bn_fwd: x, y, gamma, beta, save_mean, save_invstd required");
-    hipLaunchKernelGGL(bn_fwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
+    int sh, ept;
+    if (bn_reg_plan(a, sh, ept)) {
+        if (ept <= 16) hipLaunchKernelGGL(bn_fwd_reg_kernel<16>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a, sh);
+        else hipLaunchKernelGGL(bn_fwd_reg_kernel<64>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a, sh);
+    } else hipLaunchKernelGGL(bn_fwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
     return launch_ok("bn_fwd launch failed");
 }
 
@@ -250,7 +355,11 @@ extern "C" int pg_bn_bwd(const pg_bn_args* a, void* stream) {
     if (int e = bn_check(a)) return e;
     if (!a->x || !a->dy || !a->dx || !a->gamma || !a->save_mean || !a->save_invstd || !a->dgamma || !a->dbeta)
         return pg_fail(PG_ERR_NULL, "bn_bwd: x, dy, dx, gamma, save_mean, save_invstd, dgamma, dbeta required");
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
+    int sh, ept;
+    if (bn_reg_plan(a, sh, ept)) {
+        if (ept <= 16) hipLaunchKernelGGL(bn_bwd_reg_kernel<16>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a, sh);
+        else hipLaunchKernelGGL(bn_bwd_reg_kernel<64>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a, sh);
+    } else hipLaunchKernelGGL(bn_bwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
     return launch_ok("bn_bwd launch failed");
 }
 
