@@ -224,7 +224,7 @@ def dp_diagnostics(torch, dist, trainer, batch, world, step_ms):
     exposed = max(0.0, step_ms - nocomm)
     out.update({"allreduce_alone_ms": {k: round(v, 3) for k, v in alone.items()}, "allreduce_alone_total_ms": round(total, 3),
                 "allreduce_payload_bytes": payload,
-                "allreduce_busbw_GBps": round(payload * 2 * (world - 1) / world / (total * 1e-3) / 1e9, 1),
+                "allreduce_busbw_GBps": round(payload * 2 * (world - 1) / max(world, 1) / (total * 1e-3) / 1e9, 1),
                 "step_ms_compute_only": round(nocomm, 3), "comm_exposed_ms": round(exposed, 3),
                 "comm_hidden_frac": round(max(0.0, min(1.0, 1.0 - exposed / total)), 4) if total > 0 else None})
     return out
@@ -238,7 +238,8 @@ def run_train(a, torch, dist, world, rank, local):
     peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     torch.manual_seed(0)
     model = UNetModel(C, 2 * C, gpu_ids=[local], precision=a.precision)
-    trainer = Trainer(model, lr=1e-3, grad_compress=None if a.grad_compress == "none" else a.grad_compress)
+    selftest = a.dp_selftest and world == 1         # one-rank RCCL group: every collective of the N > 1 path is really issued
+    trainer = Trainer(model, lr=1e-3, grad_compress=None if a.grad_compress == "none" else a.grad_compress, always_reduce=selftest)
     batch = synthetic_batch(torch, B, C, L, 1 + rank)
 
     def sync():
@@ -260,7 +261,7 @@ def run_train(a, torch, dist, world, rank, local):
         dt = float(t.item())
     loss_val = [float(v) for v in losses.cpu()]
     step_ms = dt / a.steps * 1e3
-    dp = dp_diagnostics(torch, dist, trainer, batch, world, step_ms) if world > 1 else None
+    dp = dp_diagnostics(torch, dist, trainer, batch, world, step_ms) if (world > 1 or selftest) else None
 
     fl = conv_flops(C, L, B)
     step_flops = 3 * sum(fl.values()) - fl["D0"]
@@ -434,6 +435,8 @@ def main():
                          "configs[4]'s arithmetic: bf16 operands, fp32 accumulate, fp32 tensors and master weights)")
     ap.add_argument("--grad-compress", choices=["none", "bf16"], default="none",
                     help="N > 1: payload of the gradient all-reduce (bf16 halves the xGMI bytes; default fp32)")
+    ap.add_argument("--dp-selftest", action="store_true",
+                    help="N = 1 only: run the data-parallel code path (bucketed RCCL all-reduce, diagnostics) on a one-rank group")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None)
@@ -458,8 +461,12 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif a.dp_selftest:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     {"train": run_train, "fwd": run_fwd, "e2e": run_e2e}[a.config](a, torch, dist, world, rank, local)
-    if world > 1:
+    if world > 1 or a.dp_selftest:
         dist.barrier()
         dist.destroy_process_group()
 

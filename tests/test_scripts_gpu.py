@@ -66,3 +66,27 @@ def test_train_accepts_the_precision_modes(tmp_path, precision):
     assert len(a) == len(b) > 0
     tol = 1e-4 if precision == "bf16x3" else 3e-2
     assert np.allclose(a, b, rtol=tol), (a, b)
+
+
+def test_bench_contract_line_and_dp_selftest(tmp_path):
+    """bench.py prints ONE JSON line with the contract's keys; `roofline` names the kernel with the largest time share and
+    carries step_frac / worst_kernel / by_kernel; --dp-selftest drives the data-parallel code path (bucketed RCCL all-reduce
+    from inside backward, parameter checksum across ranks, per-bucket timings) on a one-rank group."""
+    import json
+    out = run([os.path.join(ROOT, "bench.py"), "--channels", "32", "--frames", "64", "--batch", "4", "--steps", "2", "--warmup", "1",
+               "--no-cpu-baseline", "--no-other-precisions", "--dp-selftest"], cwd=str(tmp_path))
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "kernels"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f32" and d["unit"] == "frames/s" and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and 0 < r["step_frac"] < 1 and r["worst_kernel"]["frac"] <= r["frac"] + 1e-9
+    dom = max(r["by_kernel"].values(), key=lambda v: v["ms_per_step"])
+    assert r["kernel"].startswith(next(k for k, v in r["by_kernel"].items() if v is dom))         # the time-dominant kernel
+    assert len(d["kernels"]) == 23 and all("kernel" in v and v["kernel"].startswith("conv_") for v in d["kernels"].values())
+    dp = d["dp"]
+    assert dp["rccl_ranks"] == 1 and dp["backend"] == "nccl" and dp["replicas_identical"] is True
+    assert set(dp["allreduce_alone_ms"]) == {"U0", "U1", "U2", "U3", "D3", "D2", "D1", "D0"} and dp["step_ms_compute_only"] > 0
