@@ -373,7 +373,7 @@ def run_e2e(a, torch, dist, world, rank, local):
         ops.stft(wav, n_fft, hop, polar=True, out=polar)
         if record:
             ev[1].record()
-        pred = model.engine.forward(polar[:, 0], update_stats=False)
+        pred = model.engine.forward(polar[:, 0], update_stats=False, inference=True)
         if record:
             ev[2].record()
         outs = [audio.synthesize(polar[i:i + 64, 0], pred[i:i + 64, :C], hop) for i in range(0, nsig, 64)]
@@ -405,7 +405,7 @@ def run_e2e(a, torch, dist, world, rank, local):
         step(True)
     fl = conv_flops(C, frames, nsig)
     step_ms = dt / a.steps * 1e3
-    ks, by = kernel_pass(torch, ops, lambda: model.engine.forward(polar[:, 0], update_stats=False), 3, fl, peak, step_ms)
+    ks, by = kernel_pass(torch, ops, lambda: model.engine.forward(polar[:, 0], update_stats=False, inference=True), 3, fl, peak, step_ms)
     if rank != 0:
         return
     print(json.dumps({

@@ -89,6 +89,33 @@ enum { PG_OP_CONV1D_FWD = 0, PG_OP_CONV1D_DGRAD = 1, PG_OP_CONV1D_WGRAD = 2,
        PG_OP_CONVT1D_FWD = 3, PG_OP_CONVT1D_DGRAD = 4, PG_OP_CONVT1D_WGRAD = 5 };
 int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, int32_t buflen);
 
+/* ---- bf16-RESIDENT forward convolutions (BASELINE configs[4]: "bf16 MFMA convs") ----------------------------------------
+ * Same two forward ops, but the operands already live in HBM as bf16: activations (B, C, pitch) whose rows are `pitch`
+ * elements apart (pitch even, > L, elements [L, pitch) of every row ZERO -- allocate zero-filled once; producers never write
+ * the tail), weights as a bf16 shadow of the fp32 master weights in the kernels' GEMM layout (pg_shadow_weights, rebuilt
+ * whenever the masters change).  v_mfma_f32_32x32x16_bf16, fp32 accumulate.  Outputs: the fp32 result as is (y, optional: what
+ * pg_bn_fwd normalises) and / or up to two bf16 copies stored already activated for the next layer.  Geometries: the U-Net's
+ * (k, stride) pairs with Cin a multiple of 32 / min(taps per phase, 32); others return PG_ERR_UNSUPPORTED (use pg_conv*_fwd). */
+typedef struct pg_convh_args {
+    int32_t B, Cin, Cout, Lin, Lout, k, stride, pad;
+    int32_t transposed;              /* 0: nn.Conv1d forward (model.py:77-78), 1: nn.ConvTranspose1d forward (model.py:88-102) */
+    int32_t schedule;                /* as pg_conv_args.schedule */
+    const uint16_t* x; int64_t x_bs; /* bf16 (B, Cin, x_pitch), batch stride in elements */
+    int32_t x_pitch; int32_t _pad0;
+    const uint16_t* w;               /* pg_shadow_weights output for this layer */
+    float* y; int64_t y_bs;          /* optional fp32 (B, Cout, Lout) */
+    uint16_t* yh; int64_t yh_bs; int32_t yh_pitch; int32_t yh_act;       /* optional bf16 (B, Cout, yh_pitch) = PG_ACT(result) */
+    uint16_t* yh2; int64_t yh2_bs; int32_t yh2_pitch; int32_t yh2_act;   /* optional second bf16 copy with its own activation */
+    void* workspace; int64_t workspace_bytes;   /* pg_workspace_bytes_conv() */
+} pg_convh_args;
+int pg_conv_fwd_h(const pg_convh_args* a, void* stream);
+/* bf16 shadow of one conv layer's weights: Conv1d (Cout, Cin, k) -> [o][(q, j)] (a cast); ConvTranspose1d (Cin, Cout, k) ->
+ * [(o, phase)][(q, tap)] with the taps of a phase in the order the gather-form kernel reads them.  wh: Cin*Cout*k elements. */
+int pg_shadow_weights(const float* w, uint16_t* wh, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t transposed, void* stream);
+/* fp32 (B, C, L) -> bf16 (B, C, pitch) with PG_ACT applied and the row tails zeroed (the network input of the bf16 path). */
+typedef struct pg_cast_args { int32_t B, C, L, pitch, act, _pad0; const float* x; int64_t x_bs; uint16_t* y; int64_t y_bs; } pg_cast_args;
+int pg_cast_rows_bf16(const pg_cast_args* a, void* stream);
+
 /* Train-mode batch norm over (B, L) per channel (model.py:81,83 applied to 3-D tensors; eps 1e-5, momentum
  * 0.1; biased variance normalises, unbiased variance goes to running_var). */
 typedef struct pg_bn_args {
@@ -103,6 +130,10 @@ typedef struct pg_bn_args {
     float* dgamma; float* dbeta;         /* bwd: (C), overwritten                            */
     int32_t y_act; int32_t y2_act;       /* fwd: activation applied as y is stored; optional second output y2 with  */
     float* y2;       int64_t y2_bs;      /*   its own activation (same purpose as in pg_conv_args)                  */
+    /* fwd, bf16-resident path: optional bf16 outputs (B, C, pitch) with their own activations (tails stay untouched);  */
+    /* y may then be NULL                                                                                               */
+    uint16_t* yh;  int64_t yh_bs;  int32_t yh_pitch;  int32_t yh_act;
+    uint16_t* yh2; int64_t yh2_bs; int32_t yh2_pitch; int32_t yh2_act;
 } pg_bn_args;
 int pg_bn_fwd(const pg_bn_args* a, void* stream);
 int pg_bn_bwd(const pg_bn_args* a, void* stream);

@@ -1,0 +1,146 @@
+"""GPU: the bf16-RESIDENT forward convolutions (csrc/conv_h.hip, BASELINE configs[4]) against a float64 convolution of the
+SAME bf16 operands (products of bf16 values are exact in fp32, so only the accumulation order differs: 2e-5 of max-abs), at
+every (k, stride) geometry of the U-Net, at ragged sizes (partial tiles in M and N, several samples per tile, odd frame counts
+whose last bf16 pair is half padding) and under both work decompositions; plus the helper kernels (weight shadow, row cast,
+BatchNorm's bf16 outputs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_ref  # noqa: F401  (disables oneDNN: see oracle/unet_ref.py)
+from phasegen import detgen
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd(seed, *shape):
+    return torch.from_numpy(detgen.uniform(seed, shape, -1.0, 1.0))
+
+
+# (transposed, Cin, Cout, k, s, p, Lin, B): Cin must be a multiple of 32 / min(taps per phase, 32)
+GEOMS = [
+    (False, 8, 16, 32, 2, 16, 24, 1), (False, 16, 16, 8, 1, 2, 13, 3), (False, 16, 24, 8, 2, 1, 10, 3), (False, 16, 32, 4, 2, 1, 7, 2),
+    (True, 32, 16, 8, 2, 1, 3, 3), (True, 32, 16, 8, 1, 2, 10, 3), (True, 32, 16, 32, 2, 16, 13, 1),
+    (False, 64, 160, 32, 2, 16, 128, 2), (False, 160, 136, 8, 1, 2, 65, 3), (False, 136, 130, 8, 2, 1, 62, 2), (False, 136, 260, 4, 2, 1, 29, 3),
+    (True, 264, 132, 8, 2, 1, 29, 2), (True, 264, 132, 8, 1, 2, 62, 2), (True, 200, 140, 32, 2, 16, 65, 2),
+    (False, 64, 128, 32, 2, 16, 256, 5), (True, 128, 64, 32, 2, 16, 129, 5), (True, 64, 96, 8, 1, 2, 126, 6), (False, 64, 96, 8, 2, 1, 126, 6),
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("sched", [0, 1, 2], ids=["auto", "tile-per-wg", "stream-k"])
+def test_conv_fwd_h_vs_float64_of_the_bf16_operands(geom, sched):
+    from phasegen import ops
+    tr, Cin, Cout, k, s, p, Lin, B = geom
+    x = rnd(11, B, Cin, Lin)
+    w = rnd(12, *((Cin, Cout, k) if tr else (Cout, Cin, k))) * 0.1
+    xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+    want = (F.conv_transpose1d if tr else F.conv1d)(xb.double(), wb.double(), stride=s, padding=p)
+    Lout = want.shape[2]
+    xh = ops.h_alloc(B, Cin, Lin, "cuda")
+    ops.cast_rows_bf16(x.cuda(), xh)
+    assert torch.equal(xh[:, :, :Lin].cpu(), xb) and float(xh[:, :, Lin:].abs().max()) == 0.0
+    wh = ops.shadow_weights(w.cuda(), tr, s)
+    y = torch.full((B, Cout, Lout), float("nan"), device="cuda")
+    yh, yh2 = ops.h_alloc(B, Cout, Lout, "cuda"), ops.h_alloc(B, Cout, Lout, "cuda")
+    ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y, yh=yh, yh_act=ops.ACT_LEAKY, yh2=yh2, yh2_act=ops.ACT_RELU, schedule=sched)
+    assert relerr(y, want) < 2e-5
+    # the bf16 copies are the activated fp32 result rounded once (RNE); their row tails were never written
+    yc = y.cpu()
+    assert torch.equal(yh[:, :, :Lout].cpu(), F.leaky_relu(yc, 0.2).to(torch.bfloat16))
+    assert torch.equal(yh2[:, :, :Lout].cpu(), F.relu(yc).to(torch.bfloat16))
+    assert float(yh[:, :, Lout:].abs().max()) == 0.0 and float(yh2[:, :, Lout:].abs().max()) == 0.0
+    # a bf16 output alone (no fp32 result) is allowed
+    yh3 = ops.h_alloc(B, Cout, Lout, "cuda")
+    ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, yh=yh3, schedule=sched)
+    assert torch.equal(yh3[:, :, :Lout].cpu(), yc.to(torch.bfloat16))
+
+
+def test_weight_shadow_layouts():
+    from phasegen import ops
+    w = rnd(5, 6, 4, 8)                                      # ConvTranspose1d (Cin=6, Cout=4, k=8), stride 2: 4 taps per phase
+    sh = ops.shadow_weights(w.cuda(), True, 2).cpu().view(4 * 2, 6 * 4)
+    wb = w.to(torch.bfloat16)
+    for o in range(4):
+        for phi in range(2):
+            for q in range(6):
+                for jj in range(4):
+                    assert sh[o * 2 + phi, q * 4 + jj] == wb[q, o, 2 * (3 - jj) + phi]
+    w2 = rnd(6, 5, 3, 8)                                     # Conv1d (Cout=5, Cin=3, k=8): a cast
+    assert torch.equal(ops.shadow_weights(w2.cuda(), False, 1).cpu(), w2.to(torch.bfloat16).reshape(-1))
+
+
+def test_unsupported_geometries_are_refused():
+    from phasegen import ops
+    x = ops.h_alloc(1, 12, 30, "cuda")                       # k = 5: no bf16-resident kernel
+    w = torch.zeros(12 * 8 * 5, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="not covered"):
+        ops.conv_fwd_h(x, 30, w, (12, 8, 5), 2, 1, transposed=True, yh=ops.h_alloc(1, 8, 61, "cuda"))
+    x2 = ops.h_alloc(1, 3, 24, "cuda")                       # Cin = 3 with 8 taps: 4 channels per slab needed
+    with pytest.raises(RuntimeError, match="not covered"):
+        ops.conv_fwd_h(x2, 24, torch.zeros(16 * 3 * 8, device="cuda", dtype=torch.bfloat16), (16, 3, 8), 1, 2, yh=ops.h_alloc(1, 16, 21, "cuda"))
+
+
+def test_bn_fwd_bf16_outputs():
+    from phasegen import ops
+    B, Cc, L = 5, 24, 61
+    x = rnd(21, B, Cc, L)
+    gamma, beta = rnd(22, Cc) + 1.5, rnd(23, Cc)
+    y = torch.empty(B, Cc, L, device="cuda")
+    yh, yh2 = ops.h_alloc(B, Cc, L, "cuda"), ops.h_alloc(B, Cc, L, "cuda")
+    sm, si = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    ops.bn_fwd(x.cuda(), y, gamma.cuda(), beta.cuda(), sm, si, yh=yh, yh_act=ops.ACT_LEAKY, yh2=yh2, yh2_act=ops.ACT_RELU)
+    want = F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5)
+    assert relerr(y, want) < 1e-5
+    assert torch.equal(yh[:, :, :L].cpu(), F.leaky_relu(y.cpu(), 0.2).to(torch.bfloat16)) and float(yh[:, :, L:].abs().max()) == 0.0
+    assert torch.equal(yh2[:, :, :L].cpu(), F.relu(y.cpu()).to(torch.bfloat16))
+    ops.bn_fwd(x.cuda(), None, gamma.cuda(), beta.cuda(), sm, si, yh=yh2)                # bf16 output only
+    assert torch.equal(yh2[:, :, :L].cpu(), y.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("C,L,B", [(16, 64, 3), (32, 128, 2), (1024, 256, 4)], ids=["C16", "C32", "C1024-L256-B4"])
+def test_resident_forward_equals_the_bf16_operand_forward(C, L, B):
+    """The engine's bf16-resident inference forward (activations stored as bf16 by the producers, bf16 weight shadows) feeds
+    the matrix cores exactly the operand values of the fp32-tensor kernels' bf16 mode (which round act(x) and w to bf16 when
+    fragments are loaded): per layer the two differ only by fp32 accumulation order (2e-5, tests above).  Through the whole
+    network a 1e-6 difference in a pre-rounding value occasionally lands on the other side of a bf16 rounding boundary (a
+    0.4 % step in that element), which the next layers average over thousands of terms: 1e-4 at small widths, measured
+    5e-3 at C = 1024 (bound 2e-2; the fp32 forward is 3e-2 away from both).  BatchNorm statistics included."""
+    from phasegen.model import UNetModel
+    if C <= 32:
+        pn = detgen.make_params(C, seed=0)
+        m = UNetModel(C, 2 * C, precision="bf16").load_numpy(pn)
+    else:
+        torch.manual_seed(9)
+        m = UNetModel(C, 2 * C, precision="bf16")
+    x = torch.from_numpy(detgen.make_batch(B, C, L, seed=2)[:, 0].copy()).cuda()
+    eng = m.engine
+    assert eng.resident_ok()
+    ref = eng.forward(x, update_stats=False).clone()                      # bf16 operand mode on fp32 tensors
+    got = eng.forward(x, update_stats=False, inference=True)              # bf16-resident kernels
+    assert eng.cur is None                                                # nothing kept for a backward
+    tol = 1e-4 if C <= 32 else 2e-2
+    assert relerr(got, ref) < tol
+    with pytest.raises(RuntimeError, match="before forward"):
+        eng.backward(torch.zeros_like(got))
+    # parameters changed through the supported paths invalidate the weight shadows
+    v0 = eng.arena.version
+    if C <= 32:
+        m.load_numpy(detgen.make_params(C, seed=3))
+        assert eng.arena.version > v0
+        ref2 = eng.forward(x, update_stats=False).clone()
+        assert relerr(eng.forward(x, update_stats=False, inference=True), ref2) < 1e-4 and relerr(ref2, ref) > 1e-2
+    # running statistics are updated by the resident forward exactly as by the other one
+    rm0 = {k: v.clone() for k, v in eng.arena.buffers.items()}
+    eng.forward(x, update_stats=True, inference=True)
+    rm1 = {k: v.clone() for k, v in eng.arena.buffers.items()}
+    for k in rm0:
+        eng.arena.buffers[k].copy_(rm0[k])
+    eng.forward(x, update_stats=True)
+    for k, v in eng.arena.buffers.items():
+        assert relerr(v.float(), rm1[k].float()) < tol, k

@@ -27,6 +27,11 @@ struct IgemmParams {
     float* y2; long y2_bs; float y_slope, y2_slope;   // F,T fwd: activation on store, optional second output
     float* ws;                       // stream-K partial-tile workspace: [grid][2][64][256] floats (or NULL)
     int nslab;                       // K slabs per tile
+    // bf16-resident forward kernels (conv_h.hip): x and w are bf16; rows of x are x_pitch elements apart (even, zero tail);
+    // optional bf16 outputs (B, M, yh_pitch) stored already activated.  All NULL / 0 for the fp32-tensor kernels.
+    int x_pitch;
+    unsigned short* yh; long yh_bs; int yh_pitch; float yh_slope;
+    unsigned short* yh2; long yh2_bs; int yh2_pitch; float yh2_slope;
 };
 
 }  // namespace pgconv
@@ -297,6 +302,14 @@ __device__ __forceinline__ void store_partial(float* ws, int g, int slot, const 
             for (int r = 0; r < 16; ++r) dst[((i * NB + j) * 16 + r) * NT] = acc.c[i][j][r];
 }
 
+// fp32 -> bf16, round to nearest even (a plain cast: hipcc emits v_cvt_pk_bf16_f32, NaN stays NaN)
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+// bf16 copies of a forward result (B, M, pitch), stored activated: what the bf16-resident kernels of the next layer read
+__device__ __forceinline__ void store_h(const IgemmParams& p, int b, int m, int t, float v) {
+    if (p.yh) p.yh[(long)b * p.yh_bs + (long)m * p.yh_pitch + t] = bf16_bits(act_apply(v, p.yh_slope));
+    if (p.yh2) p.yh2[(long)b * p.yh2_bs + (long)m * p.yh2_pitch + t] = bf16_bits(act_apply(v, p.yh2_slope));
+}
+
 // ---- epilogues (shared by the GEMM kernels and the fixup kernels) -------------------------------------------------
 // acc reg r of block (i,j): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31; wave (wm, wn) owns rows
 // wm*32*MB + ..., cols wn*32*NB + ...
@@ -319,8 +332,9 @@ __device__ __forceinline__ void epilogue_f(const IgemmParams& p, const AccT<MB, 
                     const int off = m * p.Ly + t;
                     float v = acc.c[i][j][r];
                     if (ep.fused) v = ep(v, b * (int)p.add_bs + off, b * (int)p.ref_bs + off);
-                    yb[off] = act_apply(v, p.y_slope);
+                    if (p.y) yb[off] = act_apply(v, p.y_slope);
                     if (p.y2) p.y2[(long)b * p.y2_bs + off] = act_apply(v, p.y2_slope);
+                    store_h(p, b, m, t, v);
                 }
             }
     }
@@ -347,8 +361,9 @@ __device__ __forceinline__ void epilogue_t(const IgemmParams& p, const AccT<MB, 
                     const int off = o * p.Ly + tau;
                     float v = acc.c[i][j][r];
                     if (ep.fused) v = ep(v, b * (int)p.add_bs + off, b * (int)p.ref_bs + off);
-                    yb[off] = act_apply(v, p.y_slope);
+                    if (p.y) yb[off] = act_apply(v, p.y_slope);
                     if (p.y2) p.y2[(long)b * p.y2_bs + off] = act_apply(v, p.y2_slope);
+                    store_h(p, b, o, tau, v);
                 }
             }
     }
@@ -449,4 +464,6 @@ hipError_t launch_im2col(int kind, const IgemmParams& p, int grid, hipStream_t s
 hipError_t launch_raw_ft(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw.hip (F / T, tile 128 x 256)
 hipError_t launch_raw_ft_tall(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw_tall.hip (256 x 128)
 hipError_t launch_raw_g(const IgemmParams& p, int grid, hipStream_t st, int prec);              // conv_raw_wgrad.hip
+hipError_t launch_h(int kind, const IgemmParams& p, int grid, hipStream_t st);                  // conv_h.hip (bf16-resident forward)
+bool h_supported(int kind, const IgemmParams& p);
 }  // namespace pgconv

@@ -1,0 +1,224 @@
+// conv_h.hip -- bf16-RESIDENT forward convolutions (BASELINE configs[4]: "bf16 MFMA convs"): conv forward (F) and transposed-
+// conv forward (T, gather form) whose operands already live in HBM as bf16 -- activations (B, C, pitch) written by the
+// producing layer's epilogue / BatchNorm, weights as a bf16 "shadow" of the fp32 master weights in the kernel's own
+// GEMM layout [row][K] (pg_shadow_weights) -- multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//
+// Why a separate kernel: in the fp32-tensor kernels' bf16 mode (conv_raw_impl.h, BF = 1) the matrix pipe is 16x faster but
+// every operand still travels as fp32 -- per 16-deep slab a wave spends 256 cycles in MFMAs and ~580 in 36 LDS reads, 24
+// conversions and the gather issue.  Here a slab is 32 deep, and per slab a wave issues
+//   A: 4 x ds_read_b128 (weights: 8 consecutive k of a row are one aligned 16-byte read, no conversion),
+//   B: 24 x ds_read(2)_b32 + 32 x v_alignbit (activations: raw bf16 row windows; a lane's 8 consecutive taps start at an
+//      arbitrary ELEMENT, i.e. at a dword + 0 or 2 bytes: five dwords are read and funnel-shifted by the lane's parity),
+// for 16 MFMAs: 2.6x fewer LDS instructions and no conversion VALU per MFMA, half the LDS-DMA instructions per k.
+//
+// Layout contract for the activation operand: rows (b, c, :) are `x_pitch` elements apart, x_pitch even, and elements
+// [L, x_pitch) of every row are ZERO (at least one): window dwords are gathered at even element offsets, so the only partly
+// valid dword is (L-1, L) for odd L, whose second half must read 0.  Producers (epilogues here, pg_bn_fwd, pg_cast_rows_bf16)
+// keep that tail zero.  K must be whole channels per slab (Q % (32 / min(taps, 32)) == 0); otherwise the caller uses the fp32-
+// tensor path.  Work decomposition, stream-K split, fixup kernels and epilogues are the shared ones (conv_common.h).
+#include "conv_common.h"
+
+namespace {
+
+constexpr int KB = 32;                    // k per slab (two MFMA k-steps of 16)
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int KW, int S, bool TKIND>
+__global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
+    constexpr int TM = RBM, TN = RBN;                 // workgroup tile 128 x 256, wave tile 64 x 128
+    constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
+    constexpr int TJ = KWP < 32 ? KWP : 32, NQ = 32 / TJ;
+    constexpr int SC = TKIND ? 1 : S;                 // window elements per column step
+    constexpr int RSD = SC == 1 ? 192 : 384;          // dwords reserved per channel window
+    constexpr int NPC = (RSD + NT - 1) / NT;          // gather pieces per thread and window
+    constexpr int TA = TM * 16;                       // dwords of the weight tile: 128 rows x 64 B (32 bf16)
+    constexpr int STG = TA + NQ * RSD;
+    // slabs per barrier: two 32-deep slabs are gathered together and multiplied one after the other where both stage pairs fit
+    // 64 KB (two workgroups per CU) -- halves the barrier / gather-burst rate; a bf16 slab is only 16 MFMAs (512 cycles) per wave
+    constexpr int SPB = 4 * STG * 4 <= 64 * 1024 ? 2 : 1;
+    constexpr int SSTG = SPB * STG;
+    static_assert(KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "taps per channel in K order");
+    static_assert(2 * SSTG * 4 <= 64 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) float lds[2 * SSTG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int Lcol = TKIND ? p.U : p.Ly;
+    const int Ktot = p.Q * KWP, Mrows = TKIND ? p.M * S : p.M;
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    const int g = xcd_remap(blockIdx.x, gridDim.x);
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);
+    int pos = split_lo(sp, g);
+    const int pos_end = split_lo(sp, g + 1);
+    int slot = 0;
+    while (pos < pos_end) {
+        const int tile = pos / p.nslab, sb = pos - tile * p.nslab;
+        const int se = min(p.nslab, sb + (pos_end - pos));
+        const int m0 = (tile / p.tilesN) * TM, n0 = (tile % p.tilesN) * TN;
+        const int b0 = n0 / Lcol, t0 = n0 - b0 * Lcol;
+        // ---- segments (samples) of the tile and their window geometry, in DWORDS of bf16 pairs --------------------------
+        // segment k holds the columns of sample b0 + k.  Its window starts at memory element pos_k (first tap of its first
+        // column), loaded from the even element pe_k = pos_k - sh_k below it.  Every middle segment has the same pos (frame 0).
+        const int nc0 = min(Lcol - t0, TN);                                       // columns of segment 0
+        const int pos_first = TKIND ? p.u_off + t0 - (TJ - 1) : S * t0 - p.p;     // memory element of window element 0, segment 0
+        const int pos_mid = TKIND ? p.u_off - (TJ - 1) : -p.p;                    //   ... of the later segments (frame 0)
+        const int sh0 = pos_first & 1, shm = pos_mid & 1;                         // (two's complement: also right for negatives)
+        const int nd0 = (SC * (nc0 - 1) + TJ + sh0 + 1) >> 1;                     // dwords of segment 0's window
+        const int ndm = (SC * (Lcol - 1) + TJ + shm + 1) >> 1;                    //   ... of a full middle segment
+
+        // ---- weight-tile gather: 16-byte pieces of the K-contiguous bf16 rows, swizzled image as in the fp32 kernels ------
+        int avoff[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int m = m0 + dma16_row(lane, wv, e);
+            avoff[e] = m < Mrows ? m * Ktot * 2 + dma16_kc(lane) * 4 : FAR;
+        }
+        // ---- window gather: this thread owns window dwords v = tid + 256 e of every channel ----------------------------
+        int voff[NPC];
+#pragma unroll
+        for (int e = 0; e < NPC; ++e) {
+            const int v = tid + NT * e;
+            int k, dl;
+            if (v < nd0) { k = 0; dl = v; } else { k = 1 + (v - nd0) / ndm; dl = (v - nd0) - (k - 1) * ndm; }
+            const int e0 = (k ? pos_mid - shm : pos_first - sh0) + 2 * dl;       // even memory element of this dword
+            const int b = b0 + k;
+            const bool ok = b < p.B && e0 >= 0 && e0 < p.Lx && k * Lcol < t0 + TN;
+            voff[e] = ok ? (b * (int)p.x_bs + e0) * 2 : FAR;
+        }
+        // ---- fragment bases: dword and parity of window element 0 of each of this lane's 4 columns -----------------------
+        int bdw[4], bsh[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int c = wn * 128 + jb * 32 + r, seg = (t0 + c) / Lcol;
+            const int cin = seg ? (t0 + c) - seg * Lcol : c;                      // column inside its segment
+            const int el = SC * cin + (seg ? shm : sh0);                          // window element of tap 0
+            bdw[jb] = (seg ? nd0 + (seg - 1) * ndm : 0) + (el >> 1);
+            bsh[jb] = (el & 1) << 4;                                              // funnel shift in bits
+        }
+        AccR acc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc.c[i][j][q] = 0.f;
+
+#define H_ISSUE(STAGE_PTR, SLAB)                                                                              \
+    {   float* const As = (STAGE_PTR) + wv * 64; float* const Bw = (STAGE_PTR) + TA + wv * 64;               \
+        const int k0 = (SLAB) * KB;                                                                          \
+        if (k0 < Ktot) {                                                                                     \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], k0 * 2); \
+            const int q0 = k0 / KWP;                                                                         \
+            _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                              \
+                const int sq = (q0 + qi) * p.x_pitch * 2 + (KWP > 32 ? 0 : 0);                               \
+                _Pragma("unroll") for (int e = 0; e < NPC; ++e)                                              \
+                    if (e * NT + wv * 64 < RSD) dma4s(rx, Bw + qi * RSD + e * NT, voff[e], sq);              \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+#define H_MMA(STAGE_PTR)                                                                                     \
+            {                                                                                                \
+                const float* As = (STAGE_PTR);                                                               \
+                typedef const __attribute__((address_space(3))) unsigned* lds_u32;                           \
+                const lds_u32 Bd = (lds_u32)((STAGE_PTR) + TA);                                              \
+                const int sw = (r >> 2) & 3;                                                                 \
+                const float* ap = As + (wm * 64 + r) * 16;                                                   \
+                _Pragma("unroll") for (int s = 0; s < 2; ++s) {      /* MFMA k-steps: k = 16 s + 8 h + (0 .. 7) */ \
+                    s16x8 a[2], b[4];                                                                        \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
+                        a[i] = __builtin_bit_cast(s16x8, *reinterpret_cast<const f32x4*>(ap + i * 32 * 16 + (((2 * s + h) ^ sw) << 2))); \
+                    _Pragma("unroll") for (int jb = 0; jb < 4; ++jb) {                                       \
+                        unsigned o[4];                                                                       \
+                        if (TJ >= 8) {                                                                       \
+                            /* channel / first tap of this lane's 8 k:  TJ 32: (0, 16 s + 8 h)  16: (s, 8 h)  8: (2 s + h, 0) */ \
+                            const int qi = TJ == 32 ? 0 : (TJ == 16 ? s : 2 * s + h);                        \
+                            const int tap0 = TJ == 32 ? 16 * s + 8 * h : (TJ == 16 ? 8 * h : 0);             \
+                            const lds_u32 bp = Bd + qi * RSD + bdw[jb] + (tap0 >> 1);                        \
+                            unsigned d[5];                                                                   \
+                            _Pragma("unroll") for (int i = 0; i < 5; ++i) d[i] = bp[i];                      \
+                            _Pragma("unroll") for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], bsh[jb]); \
+                        } else {                                         /* TJ == 4: two channels x 4 taps */ \
+                            _Pragma("unroll") for (int cc = 0; cc < 2; ++cc) {                               \
+                                const lds_u32 bp = Bd + (4 * s + 2 * h + cc) * RSD + bdw[jb];                \
+                                unsigned d[3];                                                               \
+                                _Pragma("unroll") for (int i = 0; i < 3; ++i) d[i] = bp[i];                  \
+                                _Pragma("unroll") for (int i = 0; i < 2; ++i) o[2 * cc + i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], bsh[jb]); \
+                            }                                                                                \
+                        }                                                                                    \
+                        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));                         \
+                        const u32x4v ov = {o[0], o[1], o[2], o[3]};                                          \
+                        b[jb] = __builtin_bit_cast(s16x8, ov);                                               \
+                    }                                                                                        \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
+                        _Pragma("unroll") for (int jb = 0; jb < 4; ++jb)                                     \
+                            acc.c[i][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[jb]), acc.c[i][jb], 0, 0, 0); \
+                }                                                                                            \
+            }
+
+#pragma unroll
+        for (int hf = 0; hf < SPB; ++hf) H_ISSUE(lds + hf * STG, sb + hf)
+        __syncthreads();
+        for (int sl = sb; sl < se; sl += SPB) {
+            const int cur = ((sl - sb) / SPB) & 1;
+#pragma unroll
+            for (int hf = 0; hf < SPB; ++hf) H_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, sl + SPB + hf)
+            __builtin_amdgcn_sched_barrier(0);
+            H_MMA(lds + cur * SSTG)
+            if (SPB == 2 && sl + 1 < se) H_MMA(lds + cur * SSTG + STG)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+#undef H_MMA
+#undef H_ISSUE
+        if (sb == 0 && se == p.nslab) {
+            if (TKIND) epilogue_t<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+            else epilogue_f<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+        } else store_partial(p.ws, g, slot, acc, tid);
+        pos += se - sb;
+        slot = 1;
+    }
+}
+
+template <int KW, int S, bool TK>
+hipError_t launch1(const IgemmParams& p, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv_h_kernel<KW, S, TK>), dim3(grid), dim3(NT), 0, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// window dwords per channel that the kernel reserves / needs for this problem (host-side mirror of the kernel's geometry)
+bool pgconv::h_supported(int kind, const IgemmParams& p) {
+    const bool t = kind == KIND_T;
+    if (kind == KIND_G) return false;
+    if (t) { if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2))) return false; }
+    else if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
+    const int kwp = t ? p.k / p.s : p.k, tj = kwp < 32 ? kwp : 32, nq = 32 / tj, sc = t ? 1 : p.s;
+    if (p.Q % nq || (p.x_pitch & 1) || p.x_pitch <= p.Lx) return false;
+    const int lcol = t ? p.U : p.Ly, rsd = sc == 1 ? 192 : 384;
+    // the kernel lays the samples' windows out back to back (segment 0, full middle segments, last partial one): the worst
+    // first-column position t0 must fit the reserved dwords
+    const int ndm = (sc * (lcol - 1) + tj + 2) >> 1;
+    int need = 0;
+    for (int t0 = 0; t0 < lcol; ++t0) {
+        const int nc0 = lcol - t0 < RBN ? lcol - t0 : RBN, rem = RBN - nc0;
+        int nmid = rem / lcol, nlast = rem - nmid * lcol;                        // full middle samples, columns of the last one
+        if (1 + nmid + (nlast ? 1 : 0) > p.B) { nlast = 0; if (1 + nmid > p.B) nmid = p.B - 1; }   // only B samples exist
+        const int n = ((sc * (nc0 - 1) + tj + 2) >> 1) + nmid * ndm + (nlast ? (sc * (nlast - 1) + tj + 2) >> 1 : 0);
+        if (n > need) need = n;
+    }
+    return need <= rsd;
+}
+
+hipError_t pgconv::launch_h(int kind, const IgemmParams& p, int grid, hipStream_t st) {
+    if (kind == KIND_F) {
+        if (p.k == 32) return launch1<32, 2, false>(p, grid, st);
+        if (p.k == 8 && p.s == 1) return launch1<8, 1, false>(p, grid, st);
+        if (p.k == 8) return launch1<8, 2, false>(p, grid, st);
+        return launch1<4, 2, false>(p, grid, st);
+    }
+    if (p.k == 32) return launch1<32, 2, true>(p, grid, st);
+    if (p.s == 1) return launch1<8, 1, true>(p, grid, st);
+    return launch1<8, 2, true>(p, grid, st);
+}

@@ -369,6 +369,64 @@ extern "C" int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, in
     return pg_fail(PG_ERR_UNSUPPORTED, "conv_describe: op must be a PG_OP_* value");
 }
 
+// ---- bf16-resident forward (conv_h.hip) ----------------------------------------------------------------------------------
+extern "C" int pg_conv_fwd_h(const pg_convh_args* a, void* stream) {
+    if (!a) return pg_fail(PG_ERR_NULL, "conv_fwd_h: null args");
+    if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->Lin <= 0 || a->Lout <= 0 || a->k <= 0 || a->stride <= 0 || a->pad < 0)
+        return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: non-positive dimension");
+    const bool tr = a->transposed != 0;
+    const long lo = tr ? (long)(a->Lin - 1) * a->stride - 2L * a->pad + a->k : ((long)a->Lin + 2L * a->pad - a->k) / a->stride + 1;
+    if (lo != a->Lout) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: Lout inconsistent with Lin/k/stride/pad");
+    if (!a->x || !a->w || (!a->y && !a->yh && !a->yh2)) return pg_fail(PG_ERR_NULL, "conv_fwd_h: x, w and at least one output required");
+    if (((uintptr_t)a->x & 3) || ((uintptr_t)a->w & 15) || (a->x_bs & 1) || (a->x_pitch & 1))
+        return pg_fail(PG_ERR_ALIGN, "conv_fwd_h: x must be 4-byte aligned with even pitch / batch stride, w 16-byte aligned");
+    if (a->x_pitch <= a->Lin) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: x_pitch must exceed Lin (zero tail of at least one element)");
+    if ((a->yh && a->yh_pitch < a->Lout) || (a->yh2 && a->yh2_pitch < a->Lout)) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: output pitch below Lout");
+    pg_conv_args kb = {};
+    kb.schedule = a->schedule;
+    Knobs kn; if (int e = decode_knobs(&kb, kn)) return e;
+    IgemmParams p = {};
+    p.x = reinterpret_cast<const float*>(a->x); p.x_bs = a->x_bs; p.x_pitch = a->x_pitch;
+    p.w = reinterpret_cast<const float*>(a->w);
+    p.y = a->y; p.y_bs = a->y_bs; p.y_slope = 1.0f; p.y2_slope = 1.0f;
+    p.yh = a->yh; p.yh_bs = a->yh_bs; p.yh_pitch = a->yh_pitch; p.yh_slope = act_slope(a->yh_act);
+    p.yh2 = a->yh2; p.yh2_bs = a->yh2_bs; p.yh2_pitch = a->yh2_pitch; p.yh2_slope = act_slope(a->yh2_act);
+    p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.Ly = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
+    const long xe = ((long)(p.B - 1) * p.x_bs + (long)p.Q * p.x_pitch) * 2;
+    if (xe <= 0 || xe >= 0x7ffffff0L) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: activation tensor exceeds 2 GiB (31-bit buffer offsets)");
+    p.x_bytes = (unsigned)xe;
+    const long we = (long)p.M * p.Q * p.k * 2 * (tr ? 1 : 1);
+    const int kwp = tr ? (p.k + p.s - 1) / p.s : p.k;
+    const long wbytes = tr ? (long)p.M * p.s * p.Q * kwp * 2 : we;
+    if (wbytes >= 0x7ffffff0L) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: weight shadow exceeds 2 GiB");
+    p.w_bytes = (unsigned)wbytes;
+    const Kind kind = tr ? KIND_T : KIND_F;
+    if (tr) {
+        p.u_off = p.p / p.s;
+        p.U = (p.Ly - 1 + p.p) / p.s - p.u_off + 1;
+        if (p.U <= 0) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: empty output");
+    }
+    if (!pgconv::h_supported(kind, p)) return pg_fail(PG_ERR_UNSUPPORTED, "conv_fwd_h: geometry not covered by the bf16-resident kernels (use the fp32-tensor entry points)");
+    const long rows = tr ? (long)p.M * p.s : p.M, cols = (long)p.B * (tr ? p.U : p.Ly), Ktot = (long)p.Q * kwp;
+    p.tilesM = (int)((rows + RBM - 1) / RBM);
+    p.tilesN = (int)((cols + RBN - 1) / RBN);
+    p.nslab = (int)(Ktot / 32);
+    p.ws = (float*)a->workspace;
+    const long tiles = (long)p.tilesM * p.tilesN;
+    if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: empty or oversize grid");
+    const int grid = pick_grid(tiles, p.nslab, p, a->workspace_bytes, kn.force_mode, kn.oversub, kn.contended);
+    const bool split = grid != tiles && !(tiles % grid == 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = pgconv::launch_h(kind, p, grid, st);
+    if (e == hipSuccess && split) {
+        if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+        else hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
+    return PG_OK;
+}
+
 // Workspace a caller should hand to the conv entry points (pg_conv_args.workspace) so that badly quantised tile counts
 // can be balanced over all CUs (stream-K).  Without it every call falls back to one-tile-per-workgroup scheduling.
 extern "C" int64_t pg_workspace_bytes_conv(void) { return (int64_t)MAX_STREAMK_WG * WS_PER_WG; }

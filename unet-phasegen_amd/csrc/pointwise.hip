@@ -16,6 +16,14 @@ namespace {
 // running_var gets the unbiased variance, momentum 0.1.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bn_slope(int act) { return act == PG_ACT_LEAKY02 ? 0.2f : (act == PG_ACT_RELU ? 0.0f : 1.0f); }
+__device__ __forceinline__ unsigned short to_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+// all outputs of a BatchNorm forward for element (b, c, l): fp32 y / y2 and the bf16 copies of the bf16-resident path
+__device__ __forceinline__ void bn_store(const pg_bn_args& a, int b, int c, int l, float o) {
+    if (a.y) { const float s1 = bn_slope(a.y_act); a.y[(long)b * a.y_bs + (long)c * a.L + l] = fmaxf(o, s1 * o); }   // slope 1 = identity, 0.2 = LeakyReLU, 0 = ReLU
+    if (a.y2) { const float s2 = bn_slope(a.y2_act); a.y2[(long)b * a.y2_bs + (long)c * a.L + l] = fmaxf(o, s2 * o); }
+    if (a.yh) { const float s3 = bn_slope(a.yh_act); a.yh[(long)b * a.yh_bs + (long)c * a.yh_pitch + l] = to_bf16_bits(fmaxf(o, s3 * o)); }
+    if (a.yh2) { const float s4 = bn_slope(a.yh2_act); a.yh2[(long)b * a.yh2_bs + (long)c * a.yh2_pitch + l] = to_bf16_bits(fmaxf(o, s4 * o)); }
+}
 
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const pg_bn_args a) {
     __shared__ float scratch[16];
@@ -36,14 +44,9 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const pg_bn_args a) {
     const float var = pg_block_sum(q, scratch) / (float)n;
     const float invstd = 1.0f / sqrtf(var + a.eps);
     const float g = a.gamma[c], be = a.beta[c];
-    float* yc = a.y + (long)c * a.L;
-    float* y2c = a.y2 ? a.y2 + (long)c * a.L : nullptr;
-    const float s1 = bn_slope(a.y_act), s2 = bn_slope(a.y2_act);
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const int b = e / a.L, l = e - b * a.L;
-        const float v = (xc[(long)b * a.x_bs + l] - mean) * invstd * g + be;
-        yc[(long)b * a.y_bs + l] = fmaxf(v, s1 * v);            // slope 1 = identity, 0.2 = LeakyReLU, 0 = ReLU
-        if (y2c) y2c[(long)b * a.y2_bs + l] = fmaxf(v, s2 * v);
+        bn_store(a, b, c, l, (xc[(long)b * a.x_bs + l] - mean) * invstd * g + be);
     }
     if (threadIdx.x == 0) {
         a.save_mean[c] = mean;
@@ -86,17 +89,10 @@ __global__ __launch_bounds__(256) void bn_fwd_reg_kernel(const pg_bn_args a, int
     const float var = pg_block_sum(q, scratch) / (float)n;
     const float invstd = 1.0f / sqrtf(var + a.eps);
     const float ga = a.gamma[c], be = a.beta[c];
-    float* yc = a.y + (long)c * a.L + l;
-    float* y2c = a.y2 ? a.y2 + (long)c * a.L + l : nullptr;
-    const float s1 = bn_slope(a.y_act), s2 = bn_slope(a.y2_act);
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int b = g + i * G;
-        if (lok && b < a.B) {
-            const float o = (v[i] - mean) * invstd * ga + be;
-            yc[(long)b * a.y_bs] = fmaxf(o, s1 * o);
-            if (y2c) y2c[(long)b * a.y2_bs] = fmaxf(o, s2 * o);
-        }
+        if (lok && b < a.B) bn_store(a, b, c, l, (v[i] - mean) * invstd * ga + be);
     }
     if (threadIdx.x == 0) {
         a.save_mean[c] = mean;
@@ -315,6 +311,37 @@ __global__ __launch_bounds__(256) void polar_kernel(const float* __restrict__ in
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16-resident path helpers (conv_h.hip): the weight shadow and the fp32 -> bf16 row cast.
+// ---------------------------------------------------------------------------------------------------------
+// Conv1d weights (Cout, Cin, k) are already [row = o][K = (q, j)]: a plain cast.  ConvTranspose1d weights (Cin, Cout, k) become
+// A[(o * s + phi)][q * KJ + jj'] = W[q][o][s * (KJ - 1 - jj') + phi]  (KJ = k / s taps per phase; taps stored so that window
+// positions ASCEND with jj', the order conv_h_kernel's T form reads them in).
+__global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w, unsigned short* __restrict__ wh, int Cin, int Cout, int k, int s, int transposed) {
+    const long n = (long)Cin * Cout * k;
+    const int KJ = transposed ? k / s : k;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        if (!transposed) { wh[e] = to_bf16_bits(w[e]); continue; }
+        const long Ktot = (long)Cin * KJ;
+        const long row = e / Ktot; const int kk = (int)(e - row * Ktot);
+        const int o = (int)(row / s), phi = (int)(row - (long)o * s), q = kk / KJ, jj = kk - q * KJ;
+        wh[e] = to_bf16_bits(w[((long)q * Cout + o) * k + s * (KJ - 1 - jj) + phi]);
+    }
+}
+
+// (B, C, L) fp32 rows -> (B, C, pitch) bf16 rows, activation applied first; the tail [L, pitch) of every row is zeroed.
+__global__ __launch_bounds__(256) void cast_rows_kernel(const pg_cast_args a) {
+    const long rows = (long)a.B * a.C, total = rows * a.pitch;
+    const float slope = bn_slope(a.act);
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / a.pitch; const int l = (int)(e - row * a.pitch);
+        const long b = row / a.C, c = row - b * a.C;
+        float v = 0.f;
+        if (l < a.L) { v = a.x[b * a.x_bs + c * a.L + l]; v = fmaxf(v, slope * v); }
+        a.y[b * a.y_bs + c * a.pitch + l] = to_bf16_bits(v);
+    }
+}
+
 int launch_ok(const char* what) {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, what);
@@ -339,10 +366,30 @@ bool bn_reg_plan(const pg_bn_args* a, int& lr_shift, int& ept) {
 
 }  // namespace
 
+extern "C" int pg_shadow_weights(const float* w, uint16_t* wh, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t transposed, void* stream) {
+    if (!w || !wh) return pg_fail(PG_ERR_NULL, "shadow_weights: w, wh required");
+    if (Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return pg_fail(PG_ERR_SHAPE, "shadow_weights: non-positive dimension");
+    if (transposed && k % stride) return pg_fail(PG_ERR_UNSUPPORTED, "shadow_weights: transposed convs need stride | k");
+    const long n = (long)Cin * Cout * k;
+    long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wh, Cin, Cout, k, stride, transposed);
+    return launch_ok("shadow_weights launch failed");
+}
+
+extern "C" int pg_cast_rows_bf16(const pg_cast_args* a, void* stream) {
+    if (!a || !a->x || !a->y) return pg_fail(PG_ERR_NULL, "cast_rows_bf16: x, y required");
+    if (a->B <= 0 || a->C <= 0 || a->L <= 0 || a->pitch < a->L) return pg_fail(PG_ERR_SHAPE, "cast_rows_bf16: bad sizes");
+    const long total = (long)a->B * a->C * a->pitch;
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    return launch_ok("cast_rows_bf16 launch failed");
+}
+
 extern "C" int pg_bn_fwd(const pg_bn_args* a, void* stream) {
     if (int e = bn_check(a)) return e;
-    if (!a->x || !a->y || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd)
-        return pg_fail(PG_ERR_NULL, "bn_fwd: x, y, gamma, beta, save_mean, save_invstd required");
+    if (!a->x || (!a->y && !a->yh) || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd)
+        return pg_fail(PG_ERR_NULL, "bn_fwd: x, y (or yh), gamma, beta, save_mean, save_invstd required");
+    if ((a->yh && a->yh_pitch < a->L) || (a->yh2 && a->yh2_pitch < a->L)) return pg_fail(PG_ERR_SHAPE, "bn_fwd: bf16 output pitch below L");
     int sh, ept;
     if (bn_reg_plan(a, sh, ept)) {
         if (ept <= 16) hipLaunchKernelGGL(bn_fwd_reg_kernel<16>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a, sh);

@@ -41,7 +41,25 @@ class BnArgs(C.Structure):
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("dy", C.c_void_p), ("dy_bs", C.c_int64), ("dx", C.c_void_p), ("dx_bs", C.c_int64),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
-                ("y_act", C.c_int32), ("y2_act", C.c_int32), ("y2", C.c_void_p), ("y2_bs", C.c_int64)]
+                ("y_act", C.c_int32), ("y2_act", C.c_int32), ("y2", C.c_void_p), ("y2_bs", C.c_int64),
+                ("yh", C.c_void_p), ("yh_bs", C.c_int64), ("yh_pitch", C.c_int32), ("yh_act", C.c_int32),
+                ("yh2", C.c_void_p), ("yh2_bs", C.c_int64), ("yh2_pitch", C.c_int32), ("yh2_act", C.c_int32)]
+
+
+class ConvhArgs(C.Structure):
+    """pg_convh_args: bf16-resident forward conv / transposed conv (include/phasegen.h)."""
+    _fields_ = [("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("Lin", C.c_int32), ("Lout", C.c_int32),
+                ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("transposed", C.c_int32), ("schedule", C.c_int32),
+                ("x", C.c_void_p), ("x_bs", C.c_int64), ("x_pitch", C.c_int32), ("_pad0", C.c_int32),
+                ("w", C.c_void_p), ("y", C.c_void_p), ("y_bs", C.c_int64),
+                ("yh", C.c_void_p), ("yh_bs", C.c_int64), ("yh_pitch", C.c_int32), ("yh_act", C.c_int32),
+                ("yh2", C.c_void_p), ("yh2_bs", C.c_int64), ("yh2_pitch", C.c_int32), ("yh2_act", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
+class CastArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("pitch", C.c_int32), ("act", C.c_int32), ("_pad0", C.c_int32),
+                ("x", C.c_void_p), ("x_bs", C.c_int64), ("y", C.c_void_p), ("y_bs", C.c_int64)]
 
 
 class LossArgs(C.Structure):
@@ -93,6 +111,9 @@ SYMBOLS = {
     "pg_convt1d_dgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pg_convt1d_wgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pg_conv_describe": (C.c_int, [C.POINTER(ConvArgs), C.c_int32, C.c_char_p, C.c_int32]),
+    "pg_conv_fwd_h": (C.c_int, [C.POINTER(ConvhArgs), C.c_void_p]),
+    "pg_shadow_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "pg_cast_rows_bf16": (C.c_int, [C.POINTER(CastArgs), C.c_void_p]),
     "pg_workspace_bytes_conv": (C.c_int64, []),
     "pg_bn_fwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),
     "pg_bn_bwd": (C.c_int, [C.POINTER(BnArgs), C.c_void_p]),

@@ -69,6 +69,7 @@ class _StateHolder(nn.Module):
         unexpected = [k for k in sd if k not in want]
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
+        self._arena.touch()
         with torch.no_grad():
             for k, v in sd.items():
                 if k not in want:
@@ -115,7 +116,7 @@ class UNetModel(nn.Module):
         if torch.is_grad_enabled():
             params = [self.model.param(k) for k in detgen.param_order()]
             return _UNetFn.apply(self.engine, input, *params)
-        return self.engine.forward(input).clone()
+        return self.engine.forward(input, inference=True).clone()      # no-grad: nothing is kept for a backward
 
     def save(self, path):
         torch.save(self.model.cpu().state_dict(), path)

@@ -284,8 +284,91 @@ def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False, precisi
     return dw
 
 
+# ---- bf16-resident forward path (BASELINE configs[4]; csrc/conv_h.hip) -----------------------------------------------------
+def h_pitch(L):
+    """Row pitch (elements) of a bf16 activation tensor with L frames: even, 16-byte rows, at least one zero tail element."""
+    return (L + 1 + 7) // 8 * 8
+
+
+def h_alloc(B, Cc, L, device):
+    """Zero-filled bf16 (B, C, pitch) tensor: producers only ever write frames [0, L), so the zero tails stay zero."""
+    return torch.zeros(B, Cc, h_pitch(L), device=device, dtype=torch.bfloat16)
+
+
+def _h3(t, L, name):
+    """(ptr, batch stride, pitch) of a bf16 (B, C, pitch) device view whose rows are `pitch` apart (pitch = size of dim 2)."""
+    if t is None:
+        return None, 0, 0
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 3 and t.stride(2) == 1):
+        raise ValueError(f"{name}: expected a 3-D bfloat16 device tensor with contiguous rows, got {tuple(t.shape)} {t.dtype}")
+    _on_current_device(t, name)
+    pitch = t.stride(1) if t.shape[1] > 1 else t.shape[2]
+    if pitch < L or (pitch & 1):
+        raise ValueError(f"{name}: row pitch {pitch} must be even and >= {L}")
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else t.shape[1] * pitch), pitch
+
+
+def shadow_weights(w, transposed, stride, out=None):
+    """bf16 shadow of a conv weight in the bf16-resident kernels' GEMM layout (pg_shadow_weights)."""
+    Cin, Cout, k = _geom(transposed, w)
+    if out is None:
+        out = torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
+    _lib.check(_lib.load().pg_shadow_weights(_dense(w, "w"), C.c_void_p(out.data_ptr()), Cin, Cout, k, stride, int(transposed), _stream()),
+               "shadow_weights")
+    return out
+
+
+def cast_rows_bf16(x, out, act=ACT_NONE):
+    """fp32 (B, C, L) -> bf16 (B, C, pitch) rows, activation applied, tails zeroed."""
+    a = _lib.CastArgs()
+    a.B, a.C, a.L = x.shape
+    a.act = act
+    a.x, a.x_bs = _act3(x, "x")
+    a.y, a.y_bs, a.pitch = _h3(out, x.shape[2], "out")
+    _lib.check(_lib.load().pg_cast_rows_bf16(C.byref(a), _stream()), "cast_rows_bf16")
+    return out
+
+
+def conv_fwd_h(xh, Lin, wh, w_shape, stride, pad, transposed=False, y=None, yh=None, yh_act=ACT_NONE, yh2=None, yh2_act=ACT_NONE,
+               schedule=None):
+    """bf16-resident forward conv (pg_conv_fwd_h): xh bf16 (B, Cin, pitch) holding Lin frames, wh the layer's bf16 shadow
+    (``w_shape`` = shape of the fp32 master weight).  Outputs: fp32 y (B, Cout, Lout) and / or bf16 yh / yh2 (stored activated)."""
+    if transposed:
+        Cin, Cout, k = w_shape
+    else:
+        Cout, Cin, k = w_shape
+    B = xh.shape[0]
+    a = _lib.ConvhArgs()
+    a.B, a.Cin, a.Cout, a.Lin, a.k, a.stride, a.pad, a.transposed = B, Cin, Cout, Lin, k, stride, pad, int(transposed)
+    a.Lout = convt_out_len(Lin, k, stride, pad) if transposed else conv_out_len(Lin, k, stride, pad)
+    a.schedule = _tls.schedule if schedule is None else schedule
+    if xh.shape[1] != Cin:
+        raise ValueError(f"conv_fwd_h: x has {xh.shape[1]} channels, weight expects {Cin}")
+    a.x, a.x_bs, a.x_pitch = _h3(xh, Lin + 1, "xh")
+    if wh.dtype != torch.bfloat16 or wh.numel() != Cin * Cout * k:
+        raise ValueError("conv_fwd_h: wh must be the bf16 shadow of the layer's weight (ops.shadow_weights)")
+    _on_current_device(wh, "wh")
+    a.w = wh.data_ptr()
+    if y is not None:
+        if tuple(y.shape) != (B, Cout, a.Lout):
+            raise ValueError(f"conv_fwd_h: y{tuple(y.shape)} should be {(B, Cout, a.Lout)}")
+        a.y, a.y_bs = _act3(y, "y")
+    if yh is not None:
+        a.yh, a.yh_bs, a.yh_pitch = _h3(yh, a.Lout, "yh")
+        a.yh_act = yh_act
+    if yh2 is not None:
+        a.yh2, a.yh2_bs, a.yh2_pitch = _h3(yh2, a.Lout, "yh2")
+        a.yh2_act = yh2_act
+    ws = conv_workspace(xh.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    if _timer is not None and _cur_label is not None and _cur_label not in _timer.plans:
+        _timer.plans[_cur_label] = f"conv_h_kernel<{k}, {stride}, {'true' if transposed else 'false'}>|bf16-resident"
+    _lib.check(_lib.load().pg_conv_fwd_h(C.byref(a), _stream()), "conv_fwd_h")
+    return a.Lout
+
+
 def bn_fwd(x, y, gamma, beta, save_mean, save_invstd, running_mean=None, running_var=None, eps=1e-5, momentum=0.1,
-           y_act=ACT_NONE, y2=None, y2_act=ACT_NONE):
+           y_act=ACT_NONE, y2=None, y2_act=ACT_NONE, yh=None, yh_act=ACT_NONE, yh2=None, yh2_act=ACT_NONE):
     a = _lib.BnArgs()
     a.y_act, a.y2_act = y_act, y2_act
     if y2 is not None:
@@ -293,7 +376,14 @@ def bn_fwd(x, y, gamma, beta, save_mean, save_invstd, running_mean=None, running
     a.B, a.C, a.L = x.shape
     a.eps, a.momentum = eps, momentum
     a.x, a.x_bs = _act3(x, "x")
-    a.y, a.y_bs = _act3(y, "y")
+    if yh is not None:
+        a.yh, a.yh_bs, a.yh_pitch = _h3(yh, x.shape[2], "yh")
+        a.yh_act = yh_act
+    if yh2 is not None:
+        a.yh2, a.yh2_bs, a.yh2_pitch = _h3(yh2, x.shape[2], "yh2")
+        a.yh2_act = yh2_act
+    if y is not None:
+        a.y, a.y_bs = _act3(y, "y")
     a.gamma, a.beta = _dense(gamma, "gamma"), _dense(beta, "beta")
     a.save_mean, a.save_invstd = _dense(save_mean, "save_mean"), _dense(save_invstd, "save_invstd")
     if running_mean is not None:

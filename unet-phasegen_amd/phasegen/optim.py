@@ -39,6 +39,7 @@ class Adam:
         b1, b2 = self.betas
         if self.arena is not None:
             a = self.arena
+            a.touch()
             for p in self.params:        # grads that autograd materialised outside the arena are folded back in
                 if p.grad is not None and p.grad.data_ptr() != a.g(p._pg_key).data_ptr():
                     a.g(p._pg_key).copy_(p.grad)
@@ -53,6 +54,8 @@ class Adam:
     # -- per-layer stepping (phasegen.trainer overlaps these with the rest of backward on a side stream) -------------------
     def begin_step(self):
         self.step_count += 1
+        if self.arena is not None:
+            self.arena.touch()
 
     @torch.no_grad()
     def step_range(self, start, end, grad_scale=1.0, thin=False):

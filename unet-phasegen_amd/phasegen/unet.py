@@ -68,6 +68,8 @@ class ParamArena:
             self.shapes[k], self.offsets[k] = shp, off
             off += (int(np.prod(shp)) + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
+        self.version = 0             # bumped by everything that rewrites parameters (init, load, optimiser steps): the engine's
+        #                              bf16 weight shadows are rebuilt when it changes; code that writes `flat` directly calls touch()
         self.flat = torch.zeros(off, device=device, dtype=torch.float32)
         self.grad = torch.zeros(off, device=device, dtype=torch.float32)
         self.buffers = {}
@@ -93,6 +95,9 @@ class ParamArena:
         e = max(self.offsets[k] + (int(np.prod(self.shapes[k])) + ALIGN - 1) // ALIGN * ALIGN for k in keys)
         return s, e
 
+    def touch(self):
+        self.version += 1
+
     def init_default(self, seed=None):
         """torch's default init (model.py builds stock nn.Conv1d / nn.ConvTranspose1d / BatchNorm; weights_init
         at model.py:12-20 is never called): conv weights U(+-1/sqrt(fan_in)), gamma 1, beta 0."""
@@ -109,8 +114,10 @@ class ParamArena:
                 v.fill_(1.0)
             else:
                 v.zero_()
+        self.touch()
 
     def load_numpy(self, params):
+        self.touch()
         for k in self.shapes:
             self.view(k).copy_(torch.from_numpy(np.ascontiguousarray(params[k])))
         for k in self.buffers:
@@ -187,10 +194,95 @@ class UNetEngine:
         if update_stats:
             a.buffers[key + ".num_batches_tracked"] += 1
 
+    # -- bf16-resident inference forward (BASELINE configs[4]) ----------------------------------------------------------------
+    RESIDENT_LAYERS = ("D0", "D1", "D2", "D3", "U2", "U1", "U0")       # U3 (k = 5) has no bf16-resident kernel
+
+    def resident_ok(self):
+        """bf16-resident forward: precision bf16 and channel counts the 32-deep slabs divide (C % 8 == 0)."""
+        p = self.precision if self.precision is not None else ops._tls.precision
+        return p == 1 and self.C % 8 == 0
+
+    def _shadows(self):
+        """bf16 shadows of the conv weights in the resident kernels' layout, rebuilt when the parameters have changed."""
+        if getattr(self, "_shadow_version", None) != self.arena.version:
+            self._shadow = getattr(self, "_shadow", {})
+            for name in self.RESIDENT_LAYERS:
+                key, kind, s, p = LAYERS[name]
+                self._shadow[name] = ops.shadow_weights(self.arena.p(key), kind == "t", s, out=self._shadow.get(name))
+            self._shadow_version = self.arena.version
+        return self._shadow
+
+    def _plan_h(self, B, L):
+        key = ("h", B, L)
+        if key not in self.plans:
+            C = self.C
+            L1, L2, L3, L4 = frame_plan(L)
+            dev = self.device
+
+            def z(*s):
+                return torch.empty(*s, device=dev, dtype=torch.float32)
+
+            def zh(ch, frames):
+                return ops.h_alloc(B, ch, frames, dev)       # zero-filled once: producers never write the row tails
+            f = dict(x0=zh(C, L), l0=zh(2 * C, L1), l1=zh(2 * C, L2), l2=zh(2 * C, L3),
+                     cat0=zh(4 * C, L1), cat1=zh(4 * C, L2), cat2=zh(4 * C, L3),
+                     c1=z(B, 2 * C, L2), c2=z(B, 2 * C, L3), d3=z(B, 4 * C, L4), r3=z(B, 2 * C, L3), r2=z(B, 2 * C, L2),
+                     r1=z(B, 2 * C, L1), r0=z(B, 2 * C, L), out=z(B, 2 * C, L))
+            self.plans[key] = dict(fwd=f, L=(L, L1, L2, L3, L4))
+        return self.plans[key]
+
+    def _forward_resident(self, x, update_stats):
+        """Forward with bf16-resident operands: every activation a conv reads lives in HBM as bf16 (written activated by the
+        producing conv epilogue / BatchNorm), weights come from bf16 shadows, BatchNorm statistics and outputs stay fp32.
+        No tensors are kept for backward: inference only."""
+        B, C, L = x.shape
+        plan = self._plan_h(B, L)
+        f = plan["fwd"]
+        L, L1, L2, L3, L4 = plan["L"]
+        h = 2 * C
+        sh = self._shadows()
+        a = self.arena
+
+        def conv(name, xh, Lin, **out):
+            key, kind, s, p = LAYERS[name]
+            with ops.timed(name + ".fwd"):
+                ops.conv_fwd_h(xh, Lin, sh[name], a.shapes[key], s, p, transposed=(kind == "t"), **out)
+
+        def bn(name, raw, **out):
+            key = BN_OF[name]
+            sm, si = self.bn_save[name]
+            rm = a.buffers[key + ".running_mean"] if update_stats else None
+            rv = a.buffers[key + ".running_var"] if update_stats else None
+            ops.bn_fwd(raw, out.pop("y", None), a.p(key + ".weight"), a.p(key + ".bias"), sm, si, rm, rv, **out)
+            if update_stats:
+                a.buffers[key + ".num_batches_tracked"] += 1
+
+        ops.cast_rows_bf16(x, f["x0"])
+        conv("D0", f["x0"], L, yh=f["l0"], yh_act=ACT_LEAKY, yh2=f["cat0"][:, :h], yh2_act=ACT_RELU)
+        conv("D1", f["l0"], L1, y=f["c1"])
+        bn("D1", f["c1"], yh=f["l1"], yh_act=ACT_LEAKY, yh2=f["cat1"][:, :h], yh2_act=ACT_RELU)
+        conv("D2", f["l1"], L2, y=f["c2"])
+        bn("D2", f["c2"], yh=f["l2"], yh_act=ACT_LEAKY, yh2=f["cat2"][:, :h], yh2_act=ACT_RELU)
+        conv("D3", f["l2"], L3, y=f["d3"])                                   # raw fp32: U3 (k = 5) runs on the fp32-tensor kernel
+        key, kind, s, p = LAYERS["U3"]
+        with ops.timed("U3.fwd"):
+            ops.conv_fwd(f["d3"], a.p(key), f["r3"], s, p, x_act=ACT_RELU, transposed=True, precision="bf16")
+        bn("U3", f["r3"], yh=f["cat2"][:, h:], yh_act=ACT_RELU)
+        conv("U2", f["cat2"], L3, y=f["r2"])
+        bn("U2", f["r2"], yh=f["cat1"][:, h:], yh_act=ACT_RELU)
+        conv("U1", f["cat1"], L2, y=f["r1"])
+        bn("U1", f["r1"], yh=f["cat0"][:, h:], yh_act=ACT_RELU)
+        conv("U0", f["cat0"], L1, y=f["r0"])
+        bn("U0", f["r0"], y=f["out"])
+        self.fwd_count += 1
+        self.cur = None                      # nothing kept for backward
+        return f["out"]
+
     # -- forward -----------------------------------------------------------------------------------------------
-    def forward(self, x, update_stats=True):
+    def forward(self, x, update_stats=True, inference=False):
         """x: (B, C, L) fp32 device tensor -> (B, 2C, L).  BatchNorm is ALWAYS in training mode, as in the
-        reference (no .eval() anywhere; demo.py:36 runs batch-of-1 statistics)."""
+        reference (no .eval() anywhere; demo.py:36 runs batch-of-1 statistics).  ``inference=True`` promises that no
+        backward follows: with precision bf16 the forward then runs on the bf16-resident kernels (csrc/conv_h.hip)."""
         if x.dim() != 3 or x.shape[1] != self.C:
             raise ValueError(f"UNet: expected input (B, {self.C}, L), got {tuple(x.shape)}")
         if not x.is_cuda or x.dtype != torch.float32:
@@ -200,6 +292,8 @@ class UNetEngine:
         if x.stride(2) != 1 or (x.shape[1] > 1 and x.stride(1) != x.shape[2]):
             x = x.contiguous()                   # any other layout than (batch-strided) rows of contiguous frames: one copy
         with torch.cuda.device(self.device):     # kernels launch on the CURRENT device's stream: make that the engine's
+            if inference and self.resident_ok():
+                return self._forward_resident(x, update_stats)
             return self._forward(x, update_stats)
 
     def _forward(self, x, update_stats):
