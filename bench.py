@@ -239,7 +239,8 @@ def run_train(a, torch, dist, world, rank, local):
     torch.manual_seed(0)
     model = UNetModel(C, 2 * C, gpu_ids=[local], precision=a.precision)
     selftest = a.dp_selftest and world == 1         # one-rank RCCL group: every collective of the N > 1 path is really issued
-    trainer = Trainer(model, lr=1e-3, grad_compress=None if a.grad_compress == "none" else a.grad_compress, always_reduce=selftest)
+    trainer = Trainer(model, lr=1e-3, grad_compress=None if a.grad_compress == "none" else a.grad_compress, always_reduce=selftest,
+                      overlap_adam=not a.serial_adam)
     batch = synthetic_batch(torch, B, C, L, 1 + rank)
 
     def sync():
@@ -437,6 +438,7 @@ def main():
                     help="N > 1: payload of the gradient all-reduce (bf16 halves the xGMI bytes; default fp32)")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="N = 1 only: run the data-parallel code path (bucketed RCCL all-reduce, diagnostics) on a one-rank group")
+    ap.add_argument("--serial-adam", action="store_true", help="A/B: one Adam launch after backward instead of per-layer slices on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=None)
