@@ -60,10 +60,18 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
         // of the slab is wave-uniform and rides in the SGPR offset.  Enabled where registers allow.
         constexpr bool FASTP = BF != 2 && !(KW == 4 && BF != 0);   // (the bf16-mode k = 4 kernels are at the register limit)
         constexpr bool FASTW = FASTP && KW != 4;          // SGPR-offset window gathers: k = 4 has 9 pieces per thread, their offsets spill
-        int pv[FASTP ? 2 : 1], woff[FASTW ? C::NE : 1];   // (+ window element: channel offset + position inside the window)
+        // window inside the row (the common case): the whole window set of the tile loads as 16-byte pieces -- piece pc =
+        // floats [4 pc, 4 pc + 4) of the [channel][WLP] image (WLP is a multiple of 4, so a piece never straddles channels;
+        // the source only needs dword alignment): SUB / 4 pieces = 2 wave instructions for k = 32 instead of 8
+        constexpr int NE16 = (C::SUB / 4 + NT - 1) / NT;
+        static_assert(C::WLP % 4 == 0, "16-byte window pieces");
+        int pv[FASTP ? 2 : 1], woff[FASTW ? NE16 : 1];
         if (FASTW) {
 #pragma unroll
-            for (int e = 0; e < C::NE; ++e) woff[e] = choff[e] == FAR ? FAR : choff[e] + (vv[e] + p.p) * 4;
+            for (int e = 0; e < NE16; ++e) {
+                const int f = 4 * (tid + NT * e), ql = f / C::WLP, v0 = f - ql * C::WLP;
+                woff[e] = (f < C::SUB && qbase + ql < p.Q) ? ((qbase + ql) * p.Lx + v0) * 4 : FAR;
+            }
         }
         if (FASTP) {
 #pragma unroll
@@ -105,8 +113,8 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
         const int w0 = S * gi - p.p;                   /* memory position of window element 0 */          \
         if (FASTW && kc >= 16 && gb < p.B && w0 >= 0 && w0 + C::WLP <= p.Lx) {   /* window inside the row: no per-lane checks */ \
             const int sw_ = gb * xbs4 + w0 * 4;                                                           \
-            _Pragma("unroll") for (int e = 0; e < C::NE; ++e)                                             \
-                if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) dma4s(rx, Bw + e * NT, woff[FASTW ? e : 0], sw_); \
+            _Pragma("unroll") for (int e = 0; e < NE16; ++e)                                              \
+                if (4 * (e * NT + wv * 64) < C::SUB) dma16s(rx, (STAGE_PTR) + RTILE_A + 4 * (e * NT + wv * 64), woff[FASTW ? e : 0], sw_); \
         } else {                                                                                          \
         const int sb0 = gb < p.B ? gb * xbs4 : -NEVER, sb1 = (kc < 16 && gb + 1 < p.B) ? (gb + 1) * xbs4 : -NEVER; \
         _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                               \
