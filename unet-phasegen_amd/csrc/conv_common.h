@@ -27,6 +27,7 @@ struct IgemmParams {
     float* y2; long y2_bs; float y_slope, y2_slope;   // F,T fwd: activation on store, optional second output
     float* ws;                       // stream-K partial-tile workspace: [grid][2][64][256] floats (or NULL)
     int nslab;                       // K slabs per tile
+    int whole;                       // workgroups that own one whole tile each (hybrid split; 0 = even split)
     // bf16-resident forward kernels (conv_h.hip): x and w are bf16; rows of x are x_pitch elements apart (even, zero tail);
     // optional bf16 outputs (B, M, yh_pitch) stored already activated.  All NULL / 0 for the fp32-tensor kernels.
     int x_pitch;
@@ -279,14 +280,30 @@ struct Epi {
 // segments leave their accumulators in the workspace (slot 0 = the range's first segment, slot 1 = its last) and the
 // fixup kernel adds a tile's segments in ascending workgroup order and runs the epilogue.  No atomics, no flags, no
 // inter-workgroup ordering assumption: results are bit-reproducible.
-struct Split { int total, q, r; };
-__device__ __host__ __forceinline__ Split make_split(int tiles, int nslab, int G) {
-    Split sp; sp.total = tiles * nslab; sp.q = sp.total / G; sp.r = sp.total - sp.q * G; return sp;
+// Hybrid (round 2): the first `w` workgroups own one WHOLE tile each (no partial tiles, no fixup work for them) and only the
+// remaining tiles -- a tile count slightly above a multiple of the resident slots, e.g. 1056 = 2 x 512 + 32 -- are split evenly
+// over the other G - w workgroups.  w = 0 is the plain even split.  Workgroup ids here are LOGICAL ids (logical_wg below).
+struct Split { int total, q, r, w, wn, nslab; };
+__device__ __host__ __forceinline__ Split make_split(int tiles, int nslab, int G, int w) {
+    Split sp; sp.total = tiles * nslab; sp.w = w; sp.wn = w * nslab; sp.nslab = nslab;
+    const int rest = sp.total - sp.wn, Gr = G - w;
+    sp.q = Gr > 0 ? rest / Gr : 0; sp.r = rest - sp.q * Gr;
+    return sp;
 }
-__device__ __host__ __forceinline__ int split_lo(const Split& sp, int g) { return g < sp.r ? g * (sp.q + 1) : sp.r * (sp.q + 1) + (g - sp.r) * sp.q; }
+__device__ __host__ __forceinline__ int split_lo(const Split& sp, int g) {
+    if (g < sp.w) return g * sp.nslab;
+    const int gr = g - sp.w;
+    return sp.wn + (gr < sp.r ? gr * (sp.q + 1) : sp.r * (sp.q + 1) + (gr - sp.r) * sp.q);
+}
 __device__ __host__ __forceinline__ int split_owner(const Split& sp, int x) {
-    const int big = sp.r * (sp.q + 1);
-    return x < big ? x / (sp.q + 1) : sp.r + (x - big) / sp.q;
+    if (x < sp.wn) return x / sp.nslab;
+    const int xr = x - sp.wn, big = sp.r * (sp.q + 1);
+    return sp.w + (xr < big ? xr / (sp.q + 1) : sp.r + (xr - big) / sp.q);
+}
+// hardware workgroup id -> logical id: whole-tile workgroups come first in dispatch order (they are the long ones), each class is
+// remapped so that every XCD gets a contiguous run of tiles / of remainder ranges
+__device__ __forceinline__ int logical_wg(int bid, int G, int w) {
+    return bid < w ? xcd_remap(bid, w) : w + xcd_remap(bid - w, G - w);
 }
 
 constexpr int ACC_REGS = 128;             // accumulator registers per thread in both tile configurations (8 blocks x 16)

@@ -46,8 +46,8 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
     const int Lcol = TKIND ? p.U : p.Ly;
     const int Ktot = p.Q * KWP, Mrows = TKIND ? p.M * S : p.M;
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
-    const int g = xcd_remap(blockIdx.x, gridDim.x);
-    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);
+    const int g = logical_wg(blockIdx.x, gridDim.x, p.whole);
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x, p.whole);
     int pos = split_lo(sp, g);
     const int pos_end = split_lo(sp, g + 1);
     int slot = 0;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = WN == 2 ? wv >> 1 : wv, wn = WN == 2 ? wv & 1 : 0;
     static_assert(MB * NB * 16 == ACC_REGS, "8 blocks per wave tile: the host launches 8 workgroups per tile");
     const int tile = blockIdx.x / (MB * NB), blk = blockIdx.x - tile * (MB * NB), bi = blk / NB, bj = blk - bi * NB;
-    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, G);
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, G, p.whole);
     const int first = tile * p.nslab, last = first + p.nslab - 1;
     const int g0 = split_owner(sp, first), g1 = split_owner(sp, last);
     if (g0 == g1 && split_lo(sp, g0) <= first && split_lo(sp, g0 + 1) > last) return;   // computed whole by one workgroup
@@ -110,9 +110,10 @@ int cu_count() { return pg_cu_count(); }
 // degrades gracefully when slots are taken (16 of 512 slots held: 1x split 33 -> 58 ms, one-tile-per-workgroup 32 -> 43 ms,
 // 4x split 33 -> 37 ms).  Small problems (less than 8 slabs per resident slot, or no workspace) run one tile per
 // workgroup.  mode: 0 auto, 1 force one tile per workgroup, 2 force stream-K (tests).
-int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mode, int oversub, int contended) {
+int pick_grid(long tiles, int nslab, IgemmParams& p, long ws_bytes, int mode, int oversub, int contended) {
     const long total = tiles * (long)nslab;
     const long slots = (long)cu_count() * WG_PER_CU;
+    p.whole = 0;
     // A tile count that is a whole multiple of the resident slots quantises perfectly: whole tiles per workgroup, no partial
     // tiles through the workspace and no fixup launch (measured: the fixups of the five such layers of the U-Net cost 0.5 ms
     // per step).  Not when the chip is shared (data-parallel backward beside RCCL): there the finer split bounds the tail.
@@ -130,6 +131,16 @@ int pick_grid(long tiles, int nslab, const IgemmParams& p, long ws_bytes, int mo
     const bool can = p.ws && ws_bytes >= G * WS_PER_WG && total < 0x7fffffffL;
     if (mode == 1 || !can) return (int)tiles;
     if (mode == 2) return (int)G;
+    // Hybrid: a tile count slightly above a multiple of the slots (1056, 528) runs its full waves as whole tiles and splits only
+    // the remainder over one more wave of workgroups: the same balance as the even split with (almost) no partial tiles -- the
+    // fixup then touches 32 tiles instead of 1056.  Not when the chip is shared (see above).
+    if (!contended && tiles > slots) {
+        const long whole = tiles / slots * slots, rem = tiles - whole;
+        if (rem * nslab >= slots * 8 && whole + slots <= MAX_STREAMK_WG && ws_bytes >= (whole + slots) * WS_PER_WG) {
+            p.whole = (int)whole;
+            return (int)(whole + slots);
+        }
+    }
     return total >= slots * 8 ? (int)G : (int)tiles;
 }
 
@@ -178,7 +189,7 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
         if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_raw_kernel<%d, %d, %d>", p.k, p.s, kn.prec);
         else if (raw) snprintf(name, sizeof name, "conv_raw_kernel<%d, %d, %s, %d, %d>", p.k, p.s, kind == KIND_T ? "true" : "false", kn.prec, tall ? 1 : 2);
         else snprintf(name, sizeof name, "conv_%c_kernel<%d, %d, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), spec ? p.k : 0, spec ? p.s : 0, kn.prec);
-        snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d", name, grid, tiles, p.nslab, (int)split);
+        snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", name, grid, tiles, p.nslab, (int)split, p.whole);
         return PG_OK;
     }
     hipError_t e;

@@ -17,8 +17,8 @@ namespace {
     const int kw = KW ? KW : p.k, s = S ? S : p.s;                                                  \
     const int kt = dma_kt(lane, wv);                                                                \
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];                                   \
-    const int g = xcd_remap(blockIdx.x, gridDim.x);                                                 \
-    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);                           \
+    const int g = logical_wg(blockIdx.x, gridDim.x, p.whole);                                       \
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x, p.whole);                  \
     int pos = split_lo(sp, g);                                                                      \
     const int pos_end = split_lo(sp, g + 1);                                                        \
     int slot = 0;                                                                                   \

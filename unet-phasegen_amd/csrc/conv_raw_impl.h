@@ -143,8 +143,8 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     // channel ql of the slab, taps `within ..` of W[q][o][:]
     const int pm_f = ((lane & 7) ^ (((wv & 1) << 2) | (lane >> 4))) << 2;
     const int pm_ql = pm_f / (2 * TJ), pm_within = pm_f - pm_ql * 2 * TJ;
-    const int g = xcd_remap(blockIdx.x, gridDim.x);
-    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);
+    const int g = logical_wg(blockIdx.x, gridDim.x, p.whole);
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x, p.whole);
     int pos = split_lo(sp, g);
     const int pos_end = split_lo(sp, g + 1);
     int slot = 0;

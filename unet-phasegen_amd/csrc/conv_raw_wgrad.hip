@@ -31,8 +31,8 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
     const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
     const float slopeA = act_slope(p.act_p), slopeB = act_slope(p.act_x);
     const int pbs4 = (int)p.pt_bs * 4, xbs4 = (int)p.x_bs * 4;
-    const int g = xcd_remap(blockIdx.x, gridDim.x);
-    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x);
+    const int g = logical_wg(blockIdx.x, gridDim.x, p.whole);
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x, p.whole);
     int pos = split_lo(sp, g);
     const int pos_end = split_lo(sp, g + 1);
     int slot = 0;
