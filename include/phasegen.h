@@ -110,7 +110,9 @@ typedef struct pg_convh_args {
 } pg_convh_args;
 int pg_conv_fwd_h(const pg_convh_args* a, void* stream);
 /* bf16 shadow of one conv layer's weights: Conv1d (Cout, Cin, k) -> [o][(q, j)] (a cast); ConvTranspose1d (Cin, Cout, k) ->
- * [(o, phase)][(q, tap)] with the taps of a phase in the order the gather-form kernel reads them.  wh: Cin*Cout*k elements. */
+ * [(o, phase)][(q, tap)] with the taps of a phase in the order the gather-form kernel reads them, ceil(k / stride) taps per
+ * phase rounded up to a power of two with zero weights (k = 5, stride 2: 4).  wh holds pg_shadow_elems(...) elements. */
+int64_t pg_shadow_elems(int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t transposed);
 int pg_shadow_weights(const float* w, uint16_t* wh, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t transposed, void* stream);
 /* fp32 (B, C, L) -> bf16 (B, C, pitch) with PG_ACT applied and the row tails zeroed (the network input of the bf16 path). */
 typedef struct pg_cast_args { int32_t B, C, L, pitch, act, _pad0; const float* x; int64_t x_bs; uint16_t* y; int64_t y_bs; } pg_cast_args;

@@ -29,6 +29,7 @@ GEOMS = [
     (False, 64, 160, 32, 2, 16, 128, 2), (False, 160, 136, 8, 1, 2, 65, 3), (False, 136, 130, 8, 2, 1, 62, 2), (False, 136, 260, 4, 2, 1, 29, 3),
     (True, 264, 132, 8, 2, 1, 29, 2), (True, 264, 132, 8, 1, 2, 62, 2), (True, 200, 140, 32, 2, 16, 65, 2),
     (False, 64, 128, 32, 2, 16, 256, 5), (True, 128, 64, 32, 2, 16, 129, 5), (True, 64, 96, 8, 1, 2, 126, 6), (False, 64, 96, 8, 2, 1, 126, 6),
+    (True, 32, 16, 5, 2, 1, 1, 2), (True, 264, 130, 5, 2, 1, 14, 3), (True, 128, 96, 5, 2, 1, 30, 9),      # k = 5: shadow padded to 4 taps per phase
 ]
 
 
@@ -71,16 +72,24 @@ def test_weight_shadow_layouts():
             for q in range(6):
                 for jj in range(4):
                     assert sh[o * 2 + phi, q * 4 + jj] == wb[q, o, 2 * (3 - jj) + phi]
+    w5 = rnd(7, 3, 2, 5)                                     # k = 5, stride 2: 3 and 2 real taps per phase, stored as 4 (zeros)
+    sh5 = ops.shadow_weights(w5.cuda(), True, 2).cpu().view(2 * 2, 3 * 4)
+    for o in range(2):
+        for phi in range(2):
+            for q in range(3):
+                for jj in range(4):
+                    j = 2 * (3 - jj) + phi
+                    assert sh5[o * 2 + phi, q * 4 + jj] == (w5.to(torch.bfloat16)[q, o, j] if j < 5 else 0)
     w2 = rnd(6, 5, 3, 8)                                     # Conv1d (Cout=5, Cin=3, k=8): a cast
     assert torch.equal(ops.shadow_weights(w2.cuda(), False, 1).cpu(), w2.to(torch.bfloat16).reshape(-1))
 
 
 def test_unsupported_geometries_are_refused():
     from phasegen import ops
-    x = ops.h_alloc(1, 12, 30, "cuda")                       # k = 5: no bf16-resident kernel
-    w = torch.zeros(12 * 8 * 5, device="cuda", dtype=torch.bfloat16)
+    x = ops.h_alloc(1, 16, 30, "cuda")                       # k = 7, s = 3: no bf16-resident kernel
+    w = torch.zeros(16 * 8 * 3 * 4, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="not covered"):
-        ops.conv_fwd_h(x, 30, w, (12, 8, 5), 2, 1, transposed=True, yh=ops.h_alloc(1, 8, 61, "cuda"))
+        ops.conv_fwd_h(x, 30, w, (16, 8, 7), 3, 2, transposed=True, yh=ops.h_alloc(1, 8, 90, "cuda"))
     x2 = ops.h_alloc(1, 3, 24, "cuda")                       # Cin = 3 with 8 taps: 4 channels per slab needed
     with pytest.raises(RuntimeError, match="not covered"):
         ops.conv_fwd_h(x2, 24, torch.zeros(16 * 3 * 8, device="cuda", dtype=torch.bfloat16), (16, 3, 8), 1, 2, yh=ops.h_alloc(1, 16, 21, "cuda"))

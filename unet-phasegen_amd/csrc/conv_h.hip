@@ -41,7 +41,11 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
     static_assert(2 * SSTG * 4 <= 64 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) float lds[2 * SSTG];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
+    // waves 1 (M) x 4 (N): a wave owns ALL 128 rows of the tile and 64 of its columns (4 x 2 blocks).  The B fragments -- scalar
+    // window reads + funnel shifts, the expensive operand here -- are then shared by four row blocks instead of two: per slab
+    // 12 ds_read2_b32 + 16 v_alignbit + 8 ds_read_b128 instead of 24 + 32 + 4 for the same 16 MFMAs
+    constexpr int MBW = 4, NBW = 2;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = 0, wn = wv;
     const int r = lane & 31, h = lane >> 5;
     const int Lcol = TKIND ? p.U : p.Ly;
     const int Ktot = p.Q * KWP, Mrows = TKIND ? p.M * S : p.M;
@@ -86,20 +90,20 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
             voff[e] = ok ? (b * (int)p.x_bs + e0) * 2 : FAR;
         }
         // ---- fragment bases: dword and parity of window element 0 of each of this lane's 4 columns -----------------------
-        int bdw[4], bsh[4];
+        int bdw[NBW], bsh[NBW];
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            const int c = wn * 128 + jb * 32 + r, seg = (t0 + c) / Lcol;
+        for (int jb = 0; jb < NBW; ++jb) {
+            const int c = wn * (NBW * 32) + jb * 32 + r, seg = (t0 + c) / Lcol;
             const int cin = seg ? (t0 + c) - seg * Lcol : c;                      // column inside its segment
             const int el = SC * cin + (seg ? shm : sh0);                          // window element of tap 0
             bdw[jb] = (seg ? nd0 + (seg - 1) * ndm : 0) + (el >> 1);
             bsh[jb] = (el & 1) << 4;                                              // funnel shift in bits
         }
-        AccR acc;
+        AccT<MBW, NBW> acc;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MBW; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NBW; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc.c[i][j][q] = 0.f;
 
@@ -123,12 +127,12 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
                 typedef const __attribute__((address_space(3))) unsigned* lds_u32;                           \
                 const lds_u32 Bd = (lds_u32)((STAGE_PTR) + TA);                                              \
                 const int sw = (r >> 2) & 3;                                                                 \
-                const float* ap = As + (wm * 64 + r) * 16;                                                   \
+                const float* ap = As + r * 16;                                                               \
                 _Pragma("unroll") for (int s = 0; s < 2; ++s) {      /* MFMA k-steps: k = 16 s + 8 h + (0 .. 7) */ \
-                    s16x8 a[2], b[4];                                                                        \
-                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
+                    s16x8 a[MBW], b[NBW];                                                                    \
+                    _Pragma("unroll") for (int i = 0; i < MBW; ++i)                                          \
                         a[i] = __builtin_bit_cast(s16x8, *reinterpret_cast<const f32x4*>(ap + i * 32 * 16 + (((2 * s + h) ^ sw) << 2))); \
-                    _Pragma("unroll") for (int jb = 0; jb < 4; ++jb) {                                       \
+                    _Pragma("unroll") for (int jb = 0; jb < NBW; ++jb) {                                     \
                         unsigned o[4];                                                                       \
                         if (TJ >= 8) {                                                                       \
                             /* channel / first tap of this lane's 8 k:  TJ 32: (0, 16 s + 8 h)  16: (s, 8 h)  8: (2 s + h, 0) */ \
@@ -150,8 +154,8 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
                         const u32x4v ov = {o[0], o[1], o[2], o[3]};                                          \
                         b[jb] = __builtin_bit_cast(s16x8, ov);                                               \
                     }                                                                                        \
-                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
-                        _Pragma("unroll") for (int jb = 0; jb < 4; ++jb)                                     \
+                    _Pragma("unroll") for (int i = 0; i < MBW; ++i)                                          \
+                        _Pragma("unroll") for (int jb = 0; jb < NBW; ++jb)                                   \
                             acc.c[i][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[jb]), acc.c[i][jb], 0, 0, 0); \
                 }                                                                                            \
             }
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
 #undef H_MMA
 #undef H_ISSUE
         if (sb == 0 && se == p.nslab) {
-            if (TKIND) epilogue_t<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
-            else epilogue_f<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+            if (TKIND) epilogue_t<S, MBW, NBW>(p, acc, m0, n0, lane, wm, wn);
+            else epilogue_f<S, MBW, NBW>(p, acc, m0, n0, lane, wm, wn);
         } else store_partial(p.ws, g, slot, acc, tid);
         pos += se - sb;
         slot = 1;
@@ -192,9 +196,9 @@ hipError_t launch1(const IgemmParams& p, int grid, hipStream_t st) {
 bool pgconv::h_supported(int kind, const IgemmParams& p) {
     const bool t = kind == KIND_T;
     if (kind == KIND_G) return false;
-    if (t) { if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2))) return false; }
+    if (t) { if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 5 && p.s == 2))) return false; }
     else if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
-    const int kwp = t ? p.k / p.s : p.k, tj = kwp < 32 ? kwp : 32, nq = 32 / tj, sc = t ? 1 : p.s;
+    const int kwp = t ? pg_shadow_taps(p.k, p.s) : p.k, tj = kwp < 32 ? kwp : 32, nq = 32 / tj, sc = t ? 1 : p.s;
     if (p.Q % nq || (p.x_pitch & 1) || p.x_pitch <= p.Lx) return false;
     const int lcol = t ? p.U : p.Ly, rsd = sc == 1 ? 192 : 384;
     // the kernel lays the samples' windows out back to back (segment 0, full middle segments, last partial one): the worst
@@ -220,5 +224,5 @@ hipError_t pgconv::launch_h(int kind, const IgemmParams& p, int grid, hipStream_
     }
     if (p.k == 32) return launch1<32, 2, true>(p, grid, st);
     if (p.s == 1) return launch1<8, 1, true>(p, grid, st);
-    return launch1<8, 2, true>(p, grid, st);
+    return launch1<8, 2, true>(p, grid, st);      // k = 8 and k = 5 (shadow padded to 4 taps per phase with zero weights)
 }

@@ -45,7 +45,9 @@ namespace {
 // WN = waves of the GEMM kernel along N (2: tile 64 MB x 64 NB; 1: the raw "tall" tile 128 MB x 32 NB).
 template <int KIND, int MB, int NB, int WN = 2>
 __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int G) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = WN == 2 ? wv >> 1 : wv, wn = WN == 2 ? wv & 1 : 0;
+    // WN = waves of the GEMM kernel along N: 2 -> 2 x 2 waves, 1 -> 4 x 1 (tall raw tile), 4 -> 1 x 4 (bf16-resident kernels)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = WN == 2 ? wv >> 1 : (WN == 4 ? 0 : wv), wn = WN == 2 ? wv & 1 : (WN == 4 ? wv : 0);
     static_assert(MB * NB * 16 == ACC_REGS, "8 blocks per wave tile: the host launches 8 workgroups per tile");
     const int tile = blockIdx.x / (MB * NB), blk = blockIdx.x - tile * (MB * NB), bi = blk / NB, bj = blk - bi * NB;
     const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, G, p.whole);
@@ -407,7 +409,7 @@ extern "C" int pg_conv_fwd_h(const pg_convh_args* a, void* stream) {
     if (xe <= 0 || xe >= 0x7ffffff0L) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: activation tensor exceeds 2 GiB (31-bit buffer offsets)");
     p.x_bytes = (unsigned)xe;
     const long we = (long)p.M * p.Q * p.k * 2 * (tr ? 1 : 1);
-    const int kwp = tr ? (p.k + p.s - 1) / p.s : p.k;
+    const int kwp = tr ? pg_shadow_taps(p.k, p.s) : p.k;
     const long wbytes = tr ? (long)p.M * p.s * p.Q * kwp * 2 : we;
     if (wbytes >= 0x7ffffff0L) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: weight shadow exceeds 2 GiB");
     p.w_bytes = (unsigned)wbytes;
@@ -430,8 +432,8 @@ extern "C" int pg_conv_fwd_h(const pg_convh_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = pgconv::launch_h(kind, p, grid, st);
     if (e == hipSuccess && split) {
-        if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
-        else hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+        if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 4, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+        else hipLaunchKernelGGL((conv_fixup_kernel<1, 4, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
         e = hipGetLastError();
     }
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));

@@ -6,6 +6,8 @@
 int pg_fail(int code, const char* msg);
 // Number of CUs of the current device (immutable per device; cached).
 int pg_cu_count();
+// taps per output phase in a transposed conv's bf16 weight shadow (pointwise.hip)
+int pg_shadow_taps(int k, int stride);
 
 // Wave(64)-level and block-level sum reductions (wavefront shuffles, then 4..16 partials through LDS).
 __device__ __forceinline__ float pg_wave_sum(float v) {

@@ -315,17 +315,18 @@ __global__ __launch_bounds__(256) void polar_kernel(const float* __restrict__ in
 // bf16-resident path helpers (conv_h.hip): the weight shadow and the fp32 -> bf16 row cast.
 // ---------------------------------------------------------------------------------------------------------
 // Conv1d weights (Cout, Cin, k) are already [row = o][K = (q, j)]: a plain cast.  ConvTranspose1d weights (Cin, Cout, k) become
-// A[(o * s + phi)][q * KJ + jj'] = W[q][o][s * (KJ - 1 - jj') + phi]  (KJ = k / s taps per phase; taps stored so that window
-// positions ASCEND with jj', the order conv_h_kernel's T form reads them in).
-__global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w, unsigned short* __restrict__ wh, int Cin, int Cout, int k, int s, int transposed) {
-    const long n = (long)Cin * Cout * k;
-    const int KJ = transposed ? k / s : k;
+// A[(o * s + phi)][q * KJ + jj'] = W[q][o][s * (KJ - 1 - jj') + phi]  (KJ = taps per phase, ceil(k / s) rounded up to a power
+// of two with zero weights for the taps that do not exist -- k = 5, s = 2 is stored as 4 taps per phase; taps are stored so
+// that window positions ASCEND with jj', the order conv_h_kernel's T form reads them in).
+__global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w, unsigned short* __restrict__ wh, int Cin, int Cout, int k, int s, int transposed, int KJ) {
+    const long n = transposed ? (long)Cin * Cout * s * KJ : (long)Cin * Cout * k;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         if (!transposed) { wh[e] = to_bf16_bits(w[e]); continue; }
         const long Ktot = (long)Cin * KJ;
         const long row = e / Ktot; const int kk = (int)(e - row * Ktot);
         const int o = (int)(row / s), phi = (int)(row - (long)o * s), q = kk / KJ, jj = kk - q * KJ;
-        wh[e] = to_bf16_bits(w[((long)q * Cout + o) * k + s * (KJ - 1 - jj) + phi]);
+        const int j = s * (KJ - 1 - jj) + phi;            // taps past k (KJ rounded up to a power of two; k = 5: 3 -> 4) are zero
+        wh[e] = j < k ? to_bf16_bits(w[((long)q * Cout + o) * k + j]) : (unsigned short)0;
     }
 }
 
@@ -366,13 +367,19 @@ bool bn_reg_plan(const pg_bn_args* a, int& lr_shift, int& ept) {
 
 }  // namespace
 
+// taps per output phase of a transposed conv in the shadow layout: ceil(k / stride) rounded up to a power of two
+int pg_shadow_taps(int k, int stride) { int kj = (k + stride - 1) / stride, p2 = 1; while (p2 < kj) p2 <<= 1; return p2; }
+extern "C" int64_t pg_shadow_elems(int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t transposed) {
+    return transposed ? (int64_t)Cin * Cout * stride * pg_shadow_taps(k, stride) : (int64_t)Cin * Cout * k;
+}
+
 extern "C" int pg_shadow_weights(const float* w, uint16_t* wh, int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t transposed, void* stream) {
     if (!w || !wh) return pg_fail(PG_ERR_NULL, "shadow_weights: w, wh required");
     if (Cin <= 0 || Cout <= 0 || k <= 0 || stride <= 0) return pg_fail(PG_ERR_SHAPE, "shadow_weights: non-positive dimension");
-    if (transposed && k % stride) return pg_fail(PG_ERR_UNSUPPORTED, "shadow_weights: transposed convs need stride | k");
-    const long n = (long)Cin * Cout * k;
+    const int KJ = pg_shadow_taps(k, stride);
+    const long n = transposed ? (long)Cin * Cout * stride * KJ : (long)Cin * Cout * k;
     long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wh, Cin, Cout, k, stride, transposed);
+    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wh, Cin, Cout, k, stride, transposed, KJ);
     return launch_ok("shadow_weights launch failed");
 }
 

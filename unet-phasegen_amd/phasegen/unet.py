@@ -195,7 +195,7 @@ class UNetEngine:
             a.buffers[key + ".num_batches_tracked"] += 1
 
     # -- bf16-resident inference forward (BASELINE configs[4]) ----------------------------------------------------------------
-    RESIDENT_LAYERS = ("D0", "D1", "D2", "D3", "U2", "U1", "U0")       # U3 (k = 5) has no bf16-resident kernel
+    RESIDENT_LAYERS = ("D0", "D1", "D2", "D3", "U3", "U2", "U1", "U0")  # U3 (k = 5): shadow padded to 4 taps per phase
 
     def resident_ok(self):
         """bf16-resident forward: precision bf16 and channel counts the 32-deep slabs divide (C % 8 == 0)."""
@@ -226,7 +226,7 @@ class UNetEngine:
                 return ops.h_alloc(B, ch, frames, dev)       # zero-filled once: producers never write the row tails
             f = dict(x0=zh(C, L), l0=zh(2 * C, L1), l1=zh(2 * C, L2), l2=zh(2 * C, L3),
                      cat0=zh(4 * C, L1), cat1=zh(4 * C, L2), cat2=zh(4 * C, L3),
-                     c1=z(B, 2 * C, L2), c2=z(B, 2 * C, L3), d3=z(B, 4 * C, L4), r3=z(B, 2 * C, L3), r2=z(B, 2 * C, L2),
+                     d3=zh(4 * C, L4), c1=z(B, 2 * C, L2), c2=z(B, 2 * C, L3), r3=z(B, 2 * C, L3), r2=z(B, 2 * C, L2),
                      r1=z(B, 2 * C, L1), r0=z(B, 2 * C, L), out=z(B, 2 * C, L))
             self.plans[key] = dict(fwd=f, L=(L, L1, L2, L3, L4))
         return self.plans[key]
@@ -263,10 +263,8 @@ class UNetEngine:
         bn("D1", f["c1"], yh=f["l1"], yh_act=ACT_LEAKY, yh2=f["cat1"][:, :h], yh2_act=ACT_RELU)
         conv("D2", f["l1"], L2, y=f["c2"])
         bn("D2", f["c2"], yh=f["l2"], yh_act=ACT_LEAKY, yh2=f["cat2"][:, :h], yh2_act=ACT_RELU)
-        conv("D3", f["l2"], L3, y=f["d3"])                                   # raw fp32: U3 (k = 5) runs on the fp32-tensor kernel
-        key, kind, s, p = LAYERS["U3"]
-        with ops.timed("U3.fwd"):
-            ops.conv_fwd(f["d3"], a.p(key), f["r3"], s, p, x_act=ACT_RELU, transposed=True, precision="bf16")
+        conv("D3", f["l2"], L3, yh=f["d3"], yh_act=ACT_RELU)
+        conv("U3", f["d3"], L4, y=f["r3"])
         bn("U3", f["r3"], yh=f["cat2"][:, h:], yh_act=ACT_RELU)
         conv("U2", f["cat2"], L3, y=f["r2"])
         bn("U2", f["r2"], yh=f["cat1"][:, h:], yh_act=ACT_RELU)
