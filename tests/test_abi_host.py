@@ -113,6 +113,16 @@ def test_per_call_knobs_are_validated_and_steer_the_launch_plan():
     assert lib.pg_conv1d_fwd(ctypes.byref(_u0_args(lib, precision=5)), None) != 0
 
 
+def test_resident_geometry_query_runs_on_the_host():
+    """pg_conv_fwd_h_supported: the window-fit rule of the bf16-resident kernels, answered without pointers or a GPU."""
+    from phasegen import detgen, ops
+    shp = detgen.conv_shapes(1024)
+    assert ops.conv_fwd_h_supported(64, shp[detgen.K_D0], 256, 2, 16, False)
+    assert ops.conv_fwd_h_supported(64, shp[detgen.K_U3], 30, 2, 1, True)          # k = 5 through the 4-taps-per-phase shadow
+    assert not ops.conv_fwd_h_supported(64, shp[detgen.K_D0], 24, 2, 16, False)    # 20 samples per tile: windows do not fit
+    assert not ops.conv_fwd_h_supported(4, (30, 22, 8), 64, 2, 1, False)           # 32-deep slab = 4 channels x 8 taps: Cin % 4
+
+
 def test_thread_defaults_are_thread_local():
     """ops.set_conv_precision / set_conv_schedule are per-THREAD Python defaults that are passed per call (pg_conv_args)."""
     import threading

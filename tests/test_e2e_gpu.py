@@ -93,6 +93,26 @@ def test_e2e_chain_full_size_properties():
     assert float((out.abs().amax(dim=1) - 1).abs().max()) < 1e-6
 
 
+def test_resident_forward_falls_back_where_windows_do_not_fit():
+    """Many very short samples per 256-column tile (B = 64 clips of 24 frames) exceed the bf16-resident kernels' window
+    slots: the engine must notice BEFORE launching anything (pg_conv_fwd_h_supported) and run the fp32-tensor kernels with
+    bf16 operands instead, not raise half-way through with running statistics already updated."""
+    from phasegen import ops
+    from phasegen.model import UNetModel
+    C, B, L = 16, 64, 24
+    pn = detgen.make_params(C, seed=3)
+    m = UNetModel(C, 2 * C, precision="bf16").load_numpy(pn)
+    assert m.engine.resident_ok() and not m.engine.resident_ok(B, L) and m.engine.resident_ok(4, 64)
+    x = torch.from_numpy(detgen.make_batch(B, C, L, seed=4)[:, 0].copy()).cuda()
+    got = m.engine.forward(x, update_stats=False, inference=True)
+    with torch.no_grad():
+        want = unet_ref.unet_forward(unet_ref.to_torch(pn), x.cpu()).numpy()
+    assert relmax(got, want) < 5e-2 and bool(torch.isfinite(got).all())
+    shp = detgen.conv_shapes(1024)
+    assert ops.conv_fwd_h_supported(64, shp[detgen.K_U0], 129, 2, 16, True)
+    assert not ops.conv_fwd_h_supported(64, shp[detgen.K_U0], 13, 2, 16, True)
+
+
 def conv_oracle64(x, w, k, s, p, tr, bf16):
     """float64 convolution of the operands as the kernel sees them (bf16 mode: rounded RNE first)."""
     r = (lambda t: t.to(torch.bfloat16).double()) if bf16 else (lambda t: t.double())

@@ -383,14 +383,14 @@ extern "C" int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, in
 }
 
 // ---- bf16-resident forward (conv_h.hip) ----------------------------------------------------------------------------------
-extern "C" int pg_conv_fwd_h(const pg_convh_args* a, void* stream) {
+static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query) {
     if (!a) return pg_fail(PG_ERR_NULL, "conv_fwd_h: null args");
     if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->Lin <= 0 || a->Lout <= 0 || a->k <= 0 || a->stride <= 0 || a->pad < 0)
         return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: non-positive dimension");
     const bool tr = a->transposed != 0;
     const long lo = tr ? (long)(a->Lin - 1) * a->stride - 2L * a->pad + a->k : ((long)a->Lin + 2L * a->pad - a->k) / a->stride + 1;
     if (lo != a->Lout) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: Lout inconsistent with Lin/k/stride/pad");
-    if (!a->x || !a->w || (!a->y && !a->yh && !a->yh2)) return pg_fail(PG_ERR_NULL, "conv_fwd_h: x, w and at least one output required");
+    if (!query && (!a->x || !a->w || (!a->y && !a->yh && !a->yh2))) return pg_fail(PG_ERR_NULL, "conv_fwd_h: x, w and at least one output required");
     if (((uintptr_t)a->x & 3) || ((uintptr_t)a->w & 15) || (a->x_bs & 1) || (a->x_pitch & 1))
         return pg_fail(PG_ERR_ALIGN, "conv_fwd_h: x must be 4-byte aligned with even pitch / batch stride, w 16-byte aligned");
     if (a->x_pitch <= a->Lin) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: x_pitch must exceed Lin (zero tail of at least one element)");
@@ -420,6 +420,7 @@ extern "C" int pg_conv_fwd_h(const pg_convh_args* a, void* stream) {
         if (p.U <= 0) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: empty output");
     }
     if (!pgconv::h_supported(kind, p)) return pg_fail(PG_ERR_UNSUPPORTED, "conv_fwd_h: geometry not covered by the bf16-resident kernels (use the fp32-tensor entry points)");
+    if (query) return PG_OK;
     const long rows = tr ? (long)p.M * p.s : p.M, cols = (long)p.B * (tr ? p.U : p.Ly), Ktot = (long)p.Q * kwp;
     p.tilesM = (int)((rows + RBM - 1) / RBM);
     p.tilesN = (int)((cols + RBN - 1) / RBN);
@@ -439,6 +440,10 @@ extern "C" int pg_conv_fwd_h(const pg_convh_args* a, void* stream) {
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     return PG_OK;
 }
+
+extern "C" int pg_conv_fwd_h(const pg_convh_args* a, void* stream) { return conv_fwd_h_impl(a, stream, false); }
+// 1 if pg_conv_fwd_h covers this geometry (sizes, strides and pitches of `a`; pointers may be NULL), else 0: pure host check
+extern "C" int pg_conv_fwd_h_supported(const pg_convh_args* a) { return conv_fwd_h_impl(a, nullptr, true) == PG_OK ? 1 : 0; }
 
 // Workspace a caller should hand to the conv entry points (pg_conv_args.workspace) so that badly quantised tile counts
 // can be balanced over all CUs (stream-K).  Without it every call falls back to one-tile-per-workgroup scheduling.

@@ -112,6 +112,7 @@ SYMBOLS = {
     "pg_convt1d_wgrad": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pg_conv_describe": (C.c_int, [C.POINTER(ConvArgs), C.c_int32, C.c_char_p, C.c_int32]),
     "pg_conv_fwd_h": (C.c_int, [C.POINTER(ConvhArgs), C.c_void_p]),
+    "pg_conv_fwd_h_supported": (C.c_int, [C.POINTER(ConvhArgs)]),
     "pg_shadow_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pg_shadow_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pg_cast_rows_bf16": (C.c_int, [C.POINTER(CastArgs), C.c_void_p]),

@@ -308,6 +308,20 @@ def _h3(t, L, name):
     return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else t.shape[1] * pitch), pitch
 
 
+def conv_fwd_h_supported(B, w_shape, Lin, stride, pad, transposed):
+    """True if the bf16-resident kernels cover this layer at this batch / frame count (pg_conv_fwd_h_supported; host only)."""
+    if transposed:
+        Cin, Cout, k = w_shape
+    else:
+        Cout, Cin, k = w_shape
+    a = _lib.ConvhArgs()
+    a.B, a.Cin, a.Cout, a.Lin, a.k, a.stride, a.pad, a.transposed = B, Cin, Cout, Lin, k, stride, pad, int(transposed)
+    a.Lout = convt_out_len(Lin, k, stride, pad) if transposed else conv_out_len(Lin, k, stride, pad)
+    a.x_pitch = h_pitch(Lin)
+    a.x_bs = Cin * a.x_pitch
+    return bool(_lib.load().pg_conv_fwd_h_supported(C.byref(a)))
+
+
 def shadow_weights(w, transposed, stride, out=None):
     """bf16 shadow of a conv weight in the bf16-resident kernels' GEMM layout (pg_shadow_weights)."""
     Cin, Cout, k = _geom(transposed, w)

@@ -197,10 +197,21 @@ class UNetEngine:
     # -- bf16-resident inference forward (BASELINE configs[4]) ----------------------------------------------------------------
     RESIDENT_LAYERS = ("D0", "D1", "D2", "D3", "U3", "U2", "U1", "U0")  # U3 (k = 5): shadow padded to 4 taps per phase
 
-    def resident_ok(self):
-        """bf16-resident forward: precision bf16 and channel counts the 32-deep slabs divide (C % 8 == 0)."""
+    def resident_ok(self, B=None, L=None):
+        """bf16-resident forward: precision bf16, channel counts the 32-deep slabs divide (C % 8 == 0) and -- for a given
+        batch / frame count -- every layer's windows fit the kernels' slots (many very short samples per tile do not)."""
         p = self.precision if self.precision is not None else ops._tls.precision
-        return p == 1 and self.C % 8 == 0
+        if p != 1 or self.C % 8:
+            return False
+        if B is None:
+            return True
+        key = ("hok", B, L)
+        if key not in self.plans:
+            Ls = (L,) + frame_plan(L)
+            lin = {"D0": Ls[0], "D1": Ls[1], "D2": Ls[2], "D3": Ls[3], "U3": Ls[4], "U2": Ls[3], "U1": Ls[2], "U0": Ls[1]}
+            self.plans[key] = all(ops.conv_fwd_h_supported(B, self.arena.shapes[LAYERS[n][0]], lin[n], LAYERS[n][2], LAYERS[n][3],
+                                                           LAYERS[n][1] == "t") for n in self.RESIDENT_LAYERS)
+        return self.plans[key]
 
     def _shadows(self):
         """bf16 shadows of the conv weights in the resident kernels' layout, rebuilt when the parameters have changed."""
@@ -290,7 +301,7 @@ class UNetEngine:
         if x.stride(2) != 1 or (x.shape[1] > 1 and x.stride(1) != x.shape[2]):
             x = x.contiguous()                   # any other layout than (batch-strided) rows of contiguous frames: one copy
         with torch.cuda.device(self.device):     # kernels launch on the CURRENT device's stream: make that the engine's
-            if inference and self.resident_ok():
+            if inference and self.resident_ok(x.shape[0], x.shape[2]):
                 return self._forward_resident(x, update_stats)
             return self._forward(x, update_stats)
 
