@@ -173,6 +173,11 @@ typedef struct pg_stft_args {
     int32_t single_frame;   /* transform schedule: 0 (default) = 4 frames per workgroup, real FFT through an n_fft/2-point radix-4 */
     int32_t _pad0;          /*   transform (n_fft <= 2048; longer always take the other path); 1 = one frame per workgroup,       */
     const float* y; float* out; /* full-length radix-2.  Same framing; they differ in fp32 rounding only (tests, measurements).   */
+    /* Chunked source (preproc_mdb.py:66-97 without a gathered copy).  chunk_start == NULL: signal s is row s of y
+     * (n_signals, n_samples).  Otherwise signal s is the n_samples-long chunk of source row chunk_row[s] (NULL: row 0) of
+     * y (rows, src_stride) that begins at sample chunk_start[s] (0 <= start); samples at or beyond src_len read as zero --
+     * the reference's zero-padded tail (preproc_mdb.py:86-88).  Both arrays are device pointers of n_signals entries. */
+    const int64_t* chunk_start; const int32_t* chunk_row; int64_t src_len; int64_t src_stride;
 } pg_stft_args;
 int pg_stft(const pg_stft_args* a, void* stream);
 /* The integer framing map alone (bit-exact contract): idx[t, k] = sample index of tap k of frame t. */
@@ -206,6 +211,14 @@ typedef struct pg_gl_args { int32_t bins, frames; const float* S; const float* m
 int pg_gl_project(const pg_gl_args* a, void* stream);
 typedef struct pg_ola_args { int32_t n_fft, frames, hop, normalize; const float* fr; float* audio; void* workspace; int64_t workspace_bytes; } pg_ola_args;
 int pg_ola_nt(const pg_ola_args* a, void* stream);   /* workspace: 256 bytes */
+
+/* preproc_mdb.py:182: x = (x - x.mean()) / x.std() over the WHOLE array (population std).  pg_moments reduces in double and
+ * writes stats[0] = mean, stats[1] = std (device doubles); pg_standardize applies them in place.  Two launches + one
+ * elementwise pass: 4 B read for the moments, 8 B for the update, per element. */
+typedef struct pg_moments_args { int64_t n; const float* x; double* stats; void* workspace; int64_t workspace_bytes; } pg_moments_args;
+int64_t pg_workspace_bytes_moments(void);
+int pg_moments(const pg_moments_args* a, void* stream);
+int pg_standardize(float* x, int64_t n, const double* stats, void* stream);
 
 /* small helpers the training step needs on device */
 int pg_fill(float* p, int64_t n, float value, void* stream);

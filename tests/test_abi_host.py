@@ -30,7 +30,8 @@ def test_struct_sizes_match_the_header_layout():
     from phasegen import _lib
     assert ctypes.sizeof(_lib.ConvArgs) == 8 * 4 + 8 + 8 + 4 + 4 + 8 + 4 * 16 + 8 + 8 + 8 + 8 + 24 + 16   # 200
     assert _lib.ConvArgs.precision.offset == 52 and _lib.ConvArgs.schedule.offset == 148    # the two former pad words
-    assert ctypes.sizeof(_lib.StftArgs) == 48 and ctypes.sizeof(_lib.IstftArgs) == 88
+    assert ctypes.sizeof(_lib.StftArgs) == 80 and ctypes.sizeof(_lib.IstftArgs) == 88
+    assert ctypes.sizeof(_lib.MomentsArgs) == 40
     assert ctypes.sizeof(_lib.AdamArgs) == 8 + 4 * 8 + 5 * 8 + 8
     assert ctypes.sizeof(_lib.LossArgs) == 16 + 4 * 8 + 8 + 8
 

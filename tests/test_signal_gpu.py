@@ -214,6 +214,52 @@ def test_griffin_lim_vs_oracle(n_fft, hop, frames, n_iter):
     assert np.array_equal(a2, a3)
 
 
+@pytest.mark.parametrize("n_fft,hop,t_slice,single", [(64, 16, 496, 0), (64, 16, 496, 1), (2048, 512, 65024, 0), (256, 64, 1001, 0)])
+def test_stft_reads_chunks_in_place(n_fft, hop, t_slice, single):
+    """pg_stft_args.chunk_start / chunk_row (row N2, preproc_mdb.py:84-97): the STFT of chunks read in place from a
+    (channels, samples) source -- odd starts, a chunk that runs off the end (zero tail, :86-88), a chunk that begins at the
+    last sample -- equals, BIT FOR BIT, the STFT of the same chunks gathered and zero-padded on the host."""
+    from phasegen import ops
+    a_len = 3 * t_slice + 777
+    src = np.stack([detgen.make_clip(a_len, seed=60), detgen.make_clip(a_len, seed=61)])
+    starts = [0, 1, t_slice, 2 * t_slice + 333, 3 * t_slice, a_len - 5, a_len - 1, 12345 % a_len]
+    rows = [0, 1, 1, 0, 1, 0, 1, 0]
+    padded = np.concatenate([src, np.zeros((2, t_slice), np.float32)], axis=1)
+    gathered = np.stack([padded[r, s:s + t_slice] for s, r in zip(starts, rows)])
+    want = ops.stft(torch.from_numpy(gathered).cuda(), n_fft, hop, single_frame=single)
+    got = ops.stft(torch.from_numpy(src).cuda(), n_fft, hop, single_frame=single, chunk_len=t_slice,
+                   chunk_start=torch.tensor(starts, dtype=torch.int64, device="cuda"),
+                   chunk_row=torch.tensor(rows, dtype=torch.int32, device="cuda"))
+    assert got.shape == want.shape == (8, 2, n_fft // 2, 1 + t_slice // hop)
+    assert torch.equal(got, want)
+    ref = signal_ref.chunk_and_stft(gathered[3], n_fft, hop)                       # and one chunk against the oracle
+    assert np.max(np.abs(got[3].cpu().numpy() - ref)) < 2e-5 * np.max(np.abs(ref))
+    mono = ops.stft(torch.from_numpy(src[0]).cuda(), n_fft, hop, chunk_len=t_slice, single_frame=single,
+                    chunk_start=torch.tensor([starts[3]], dtype=torch.int64, device="cuda"))       # chunk_row NULL -> row 0
+    assert torch.equal(mono[0], got[3])
+    with pytest.raises(TypeError):
+        ops.stft(torch.from_numpy(src).cuda(), n_fft, hop, chunk_len=t_slice, chunk_start=torch.tensor(starts, device="cuda").int())
+
+
+@pytest.mark.parametrize("n,off", [(1 << 20, 0), (1000003, 0), (77, 0), (999999, 1), (64 * 2 * 1024 * 128, 0)])
+def test_standardize_matches_numpy(n, off):
+    """preproc_mdb.py:182 `(x - x.mean()) / x.std()`: moments against float64 numpy to 1e-12, the result against the float32
+    formula with those moments to one rounding; odd sizes and a 4-byte-aligned (not 16) start take the scalar path."""
+    from phasegen import ops
+    x = (detgen.normal(70 + off, (n + off,)) * 3.0 + 1.5).astype(np.float32)
+    base = torch.from_numpy(x).cuda()
+    view = base[off:]
+    stats = ops.standardize_(view).cpu().numpy()
+    x64 = x[off:].astype(np.float64)
+    assert abs(stats[0] - x64.mean()) < 1e-12 * max(1.0, abs(x64.mean())) * 10 and abs(stats[1] - x64.std()) < 1e-11 * x64.std()
+    want = (x[off:] - np.float32(stats[0])) / np.float32(stats[1])
+    assert np.max(np.abs(view.cpu().numpy() - want)) <= 2.4e-7 * np.max(np.abs(want))
+    if off:
+        assert float(base[0]) == float(x[0])                                     # nothing before the view was touched
+    npy = (x[off:] - x[off:].mean()) / x[off:].std()                              # numpy's own float32 reduction
+    assert np.max(np.abs(view.cpu().numpy() - npy)) < 5e-6 * np.max(np.abs(npy))
+
+
 def test_preproc_chunker_matches_reference_algorithm(tmp_path):
     """Row N2 (preproc_mdb.py:66-97,174-196): same chunk starts, zero-padded tails, STFT layout, whole-array
     normalisation and shuffled split as a numpy restatement driven by the same Generator."""

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Side-path measurements (dev tool): STFT / polar / ISTFT bandwidth, forward-only throughput (BASELINE config 2),
+"""Side-path measurements (dev tool): STFT / polar / ISTFT bandwidth, the preprocessing kernels (chunked STFT source, whole-array
+standardisation), forward-only throughput (BASELINE config 2),
 per-clip inference latency (demo.py's timed region), Griffin-Lim time."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,6 +30,15 @@ for n_fft, hop, n, nsig in ((2048, 512, 65024, 512), (1024, 256, 65280, 512)):
     p2 = torch.empty_like(out)
     ms = timeit(lambda: ops.polar(out, p2))
     print(f"polar: {ms:.3f} ms, {2*out.numel()*4/ms/1e6:.0f} GB/s")
+    # row N2: the same frames read as chunks of 8 long tracks in place (odd starts), and the whole-array standardisation
+    src = torch.randn(8, 64 * n + 999, device="cuda")
+    st = (torch.arange(nsig, device="cuda", dtype=torch.int64) // 8) * n + 1
+    rows = (torch.arange(nsig, device="cuda") % 8).int()
+    ms = timeit(lambda: ops.stft(src, n_fft, hop, out=out, chunk_start=st, chunk_row=rows, chunk_len=n))
+    print(f"stft chunked in place: {ms:.3f} ms, {byt/ms/1e6:.0f} GB/s algorithmic")
+    ms = timeit(lambda: ops.standardize_(out))
+    print(f"standardize ({out.numel()/1e6:.0f} M values): {ms:.3f} ms, {out.numel()*16/ms/1e6:.0f} GB/s (2 reads for the moments + read/write)")
+    del src
     re, im = out[:64, 0].contiguous(), out[:64, 1].contiguous()
     ms = timeit(lambda: ops.istft(re, im, hop, mode=1, normalize=True))
     print(f"istft (64 clips): {ms:.3f} ms = {64*nf/ms*1e3/1e6:.2f} M frames/s, {(2*re.numel()*4 + 64*hop*(nf-1)*4)/ms/1e6:.0f} GB/s algorithmic")

@@ -217,11 +217,65 @@ __global__ __launch_bounds__(64) void loss_final_kernel(const float* partial, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Whole-array standardisation of the feature set (preproc_mdb.py:182): moments in double (fixed reduction order:
+// per-thread grid-stride sums, wave shuffle tree, per-workgroup partials summed by one wave), then one in-place pass.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int MOM_BLOCKS = 1024;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// pass 0: sum of x; pass 1: sum of (x - mean)^2 with the mean read from stats[0] (two-pass, like numpy's std)
+__global__ __launch_bounds__(256) void moments_partial_kernel(const float* __restrict__ x, long n, const double* stats, int pass, double* partial) {
+    __shared__ double red[4];
+    const double mean = pass ? stats[0] : 0.0;
+    double acc = 0;
+    const long stride = (long)gridDim.x * 256;
+    const bool vec = (((uintptr_t)x) & 15) == 0;
+    const long n4 = vec ? (n >> 2) : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = ((const f32x4*)x)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double d = (double)v[j] - mean; acc += pass ? d * d : d; }
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const double d = (double)x[i] - mean; acc += pass ? d * d : d;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void moments_final_kernel(const double* partial, int nblocks, double n, int pass, double* stats) {
+    double acc = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) acc += partial[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) stats[pass] = pass ? sqrt(acc / n) : acc / n;
+}
+
+__global__ __launch_bounds__(256) void standardize_kernel(float* __restrict__ x, long n, const double* stats) {
+    const float mean = (float)stats[0], std = (float)stats[1];             // float32 arithmetic, as numpy on a float32 array
+    const long stride = (long)gridDim.x * 256;
+    const bool vec = (((uintptr_t)x) & 15) == 0;
+    const long n4 = vec ? (n >> 2) : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        f32x4 v = ((f32x4*)x)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (v[j] - mean) / std;
+        ((f32x4*)x)[i] = v;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] = (x[i] - mean) / std;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam defaults, single-tensor path of torch 2.x): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g g;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  28 B of HBM traffic per parameter.
 // ---------------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float omb1, float b2, float omb2,
                                          float step_size, float bc2_sqrt, float eps, float gs) {
     g *= gs;
@@ -429,6 +483,31 @@ extern "C" int pg_loss_fwd_bwd(const pg_loss_args* a, void* stream) {
     hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a, partial);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, blocks, (double)N, a->mag_weight, a->losses);
     return launch_ok("loss launch failed");
+}
+
+extern "C" int64_t pg_workspace_bytes_moments(void) { return (int64_t)MOM_BLOCKS * (int64_t)sizeof(double); }
+
+extern "C" int pg_moments(const pg_moments_args* a, void* stream) {
+    if (!a || !a->x || !a->stats || !a->workspace) return pg_fail(PG_ERR_NULL, "moments: x, stats, workspace required");
+    if (a->n <= 0) return pg_fail(PG_ERR_SHAPE, "moments: non-positive size");
+    if (a->workspace_bytes < pg_workspace_bytes_moments()) return pg_fail(PG_ERR_WORKSPACE, "moments: workspace too small");
+    if (((uintptr_t)a->x & 3) || ((uintptr_t)a->stats & 7) || ((uintptr_t)a->workspace & 7)) return pg_fail(PG_ERR_ALIGN, "moments: misaligned pointer");
+    long blocks = ((a->n >> 2) + 255) / 256; if (blocks > MOM_BLOCKS) blocks = MOM_BLOCKS; if (blocks < 1) blocks = 1;
+    double* partial = (double*)a->workspace;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(moments_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->x, (long)a->n, a->stats, pass, partial);
+        hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, (int)blocks, (double)a->n, pass, a->stats);
+    }
+    return launch_ok("moments launch failed");
+}
+
+extern "C" int pg_standardize(float* x, int64_t n, const double* stats, void* stream) {
+    if (!x || !stats) return pg_fail(PG_ERR_NULL, "standardize: x, stats required");
+    if (n <= 0) return pg_fail(PG_ERR_SHAPE, "standardize: non-positive size");
+    if (((uintptr_t)x & 3) || ((uintptr_t)stats & 7)) return pg_fail(PG_ERR_ALIGN, "standardize: misaligned pointer");
+    long blocks = ((n >> 2) + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(standardize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, stats);
+    return launch_ok("standardize launch failed");
 }
 
 extern "C" int pg_adam_step(const pg_adam_args* a, void* stream) {

@@ -60,16 +60,27 @@ __device__ __forceinline__ void fill_twiddles(float2* tw, int N) {
     }
 }
 
+// where signal `sig` lives: first sample and how many of its n_samples exist in the source (the rest read as zero)
+struct Src { const float* p; int lim; };
+__device__ __forceinline__ Src signal_src(const pg_stft_args& a, int sig) {
+    if (!a.chunk_start) return { a.y + (long)sig * a.n_samples, a.n_samples };
+    const long st = a.chunk_start[sig];
+    const long row = a.chunk_row ? a.chunk_row[sig] : 0;
+    long lim = a.src_len - st;
+    lim = lim < 0 ? 0 : (lim > a.n_samples ? a.n_samples : lim);
+    return { a.y + row * a.src_stride + st, (int)lim };
+}
+
 __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(const pg_stft_args a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     const int N = a.n_fft, bins = N >> 1;
     float2* buf0 = smem; float2* buf1 = smem + N; float2* tw = smem + 2 * N;
     const int t = blockIdx.x % a.n_frames, sig = blockIdx.x / a.n_frames;
-    const float* y = a.y + (long)sig * a.n_samples;
+    const Src src = signal_src(a, sig);
     fill_twiddles(tw, N);
     for (int k = threadIdx.x; k < N; k += blockDim.x) {
         const int idx = reflect_index(t * a.hop + k - (N >> 1), a.n_samples);
-        buf0[k] = make_float2(y[idx] * hann(k, N), 0.f);
+        buf0[k] = make_float2((idx < src.lim ? src.p[idx] : 0.f) * hann(k, N), 0.f);
     }
     __syncthreads();
     const float2* X = fft_lds(buf0, buf1, tw, N, 1.f);
@@ -220,6 +231,8 @@ __device__ __forceinline__ GroupWalk group_walk(int total) {
     return w;
 }
 
+template <bool CHUNKED>   // CHUNKED: signals are chunks of longer source rows (pg_stft_args.chunk_start); its own instantiation so
+                          // that the plain path keeps its vector loads and register budget
 __global__ __launch_bounds__(BT) void stft_frames_kernel(const pg_stft_args a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     const int N = a.n_fft, M = N >> 1;
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(BT) void stft_frames_kernel(const pg_stft_args a) {
 #pragma unroll
     for (int i = 0; i < K_ITERS; ++i)
         sincospif(-(float)(1 + threadIdx.x + i * BT) / (float)M, &ss[i], &sc[i]);   // w = exp(-2 pi i / n_fft)
-    const bool vec2 = ((a.hop | a.n_samples) & 1) == 0 && (((uintptr_t)a.y) & 7) == 0;       // sample pairs are 8 B aligned
+    const bool vec2 = !CHUNKED && ((a.hop | a.n_samples) & 1) == 0 && (((uintptr_t)a.y) & 7) == 0;   // sample pairs are 8 B aligned
     const bool vec4 = (a.n_frames & 3) == 0 && (((uintptr_t)a.out) & 15) == 0;               // row segments are 16 B aligned
     __syncthreads();
     // sample pairs of one group -> registers (windowing and the LDS write happen one iteration later, so the loads of
@@ -245,7 +258,10 @@ __global__ __launch_bounds__(BT) void stft_frames_kernel(const pg_stft_args a) {
     auto load_group = [&](int g) {
         const int sig = g / groups, t0 = (g - sig * groups) * SF;
         const int nfr = min(SF, a.n_frames - t0);
-        const float* sgn = a.y + (long)sig * a.n_samples;
+        const float* sgn; int lim;
+        if (CHUNKED) { const Src src = signal_src(a, sig); sgn = src.p; lim = src.lim; }
+        else { sgn = a.y + (long)sig * a.n_samples; lim = a.n_samples; }
+        auto at = [&](int q) { return (!CHUNKED || q < lim) ? sgn[q] : 0.f; };
 #pragma unroll
         for (int i = 0; i < M_ITERS; ++i) {
             const int m = threadIdx.x + i * BT;
@@ -256,8 +272,8 @@ __global__ __launch_bounds__(BT) void stft_frames_kernel(const pg_stft_args a) {
                     const int start = (t0 + f) * a.hop - M, p = start + 2 * m;              // frame tap k sits at start + k
                     if (start >= 0 && start + N <= a.n_samples) {
                         if (vec2) { const float2 v = *(const float2*)(sgn + p); v0 = v.x; v1 = v.y; }
-                        else { v0 = sgn[p]; v1 = sgn[p + 1]; }
-                    } else { v0 = sgn[reflect_index(p, a.n_samples)]; v1 = sgn[reflect_index(p + 1, a.n_samples)]; }
+                        else { v0 = at(p); v1 = at(p + 1); }
+                    } else { v0 = at(reflect_index(p, a.n_samples)); v1 = at(reflect_index(p + 1, a.n_samples)); }
                 }
                 pre[i][f] = make_float2(v0, v1);
             }
@@ -588,13 +604,14 @@ bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 constexpr int BATCHED_MAX_NFFT = 2048;
 size_t batched_lds(int n_fft) { return (size_t)(2 * SF * (n_fft / 2) + 3 * tw_len(n_fft / 2)) * sizeof(float2); }
 int batched_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (2 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }
+// the attribute belongs to (function, CURRENT device): set on every call (a host-side table write), so a process that drives
+// several devices is served too and nothing is cached between calls
 hipError_t batched_lds_ready() {
-    static hipError_t st = [] {
-        hipError_t e = hipFuncSetAttribute((const void*)stft_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)batched_lds(BATCHED_MAX_NFFT));
-        if (e != hipSuccess) return e;
-        return hipFuncSetAttribute((const void*)istft_frames4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)batched_lds(BATCHED_MAX_NFFT));
-    }();
-    return st;
+    const int lds = (int)batched_lds(BATCHED_MAX_NFFT);
+    hipError_t e = hipFuncSetAttribute((const void*)stft_frames_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_frames_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_frames4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return e;
 }
 
 }  // namespace
@@ -604,11 +621,14 @@ extern "C" int pg_stft(const pg_stft_args* a, void* stream) {
     if (!pow2(a->n_fft) || a->n_fft < 32 || a->n_fft > 4096) return pg_fail(PG_ERR_UNSUPPORTED, "stft: n_fft must be a power of two in [32, 4096]");
     if (a->n_signals <= 0 || a->hop <= 0 || a->n_samples <= a->n_fft / 2) return pg_fail(PG_ERR_SHAPE, "stft: bad sizes (reflect padding needs n_samples > n_fft/2)");
     if (a->n_frames != 1 + a->n_samples / a->hop) return pg_fail(PG_ERR_SHAPE, "stft: n_frames must equal 1 + n_samples / hop");
+    if (a->chunk_start && (a->src_len <= 0 || a->src_stride < a->src_len)) return pg_fail(PG_ERR_SHAPE, "stft: chunked source needs 0 < src_len <= src_stride");
+    if (!a->chunk_start && a->chunk_row) return pg_fail(PG_ERR_NULL, "stft: chunk_row without chunk_start");
     hipError_t e = batched_lds_ready();
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     if (a->n_fft <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
-        hipLaunchKernelGGL(stft_frames_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
+        if (a->chunk_start) hipLaunchKernelGGL(stft_frames_kernel<true>, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL(stft_frames_kernel<false>, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
     } else {
         const size_t lds = (size_t)(2 * a->n_fft + a->n_fft / 2) * sizeof(float2);
         hipLaunchKernelGGL(stft_kernel, dim3((unsigned)(a->n_signals * a->n_frames)), dim3(FFT_THREADS), lds, (hipStream_t)stream, *a);

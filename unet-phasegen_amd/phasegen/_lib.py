@@ -77,7 +77,13 @@ class AdamArgs(C.Structure):
 class StftArgs(C.Structure):
     _fields_ = [("n_signals", C.c_int32), ("n_samples", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32),
                 ("n_frames", C.c_int32), ("polar", C.c_int32), ("single_frame", C.c_int32), ("_pad0", C.c_int32),
-                ("y", C.c_void_p), ("out", C.c_void_p)]
+                ("y", C.c_void_p), ("out", C.c_void_p),
+                ("chunk_start", C.c_void_p), ("chunk_row", C.c_void_p), ("src_len", C.c_int64), ("src_stride", C.c_int64)]
+
+
+class MomentsArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("x", C.c_void_p), ("stats", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_int64)]
 
 
 class PolarArgs(C.Structure):
@@ -113,6 +119,9 @@ SYMBOLS = {
     "pg_conv_describe": (C.c_int, [C.POINTER(ConvArgs), C.c_int32, C.c_char_p, C.c_int32]),
     "pg_conv_fwd_h": (C.c_int, [C.POINTER(ConvhArgs), C.c_void_p]),
     "pg_conv_fwd_h_supported": (C.c_int, [C.POINTER(ConvhArgs)]),
+    "pg_workspace_bytes_moments": (C.c_int64, []),
+    "pg_moments": (C.c_int, [C.POINTER(MomentsArgs), C.c_void_p]),
+    "pg_standardize": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pg_shadow_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pg_shadow_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pg_cast_rows_bf16": (C.c_int, [C.POINTER(CastArgs), C.c_void_p]),

@@ -101,6 +101,13 @@ def _dense(t, name):
     return t.data_ptr()
 
 
+def _dense_as(t, dtype, name):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous {dtype} device tensor")
+    _on_current_device(t, name)
+    return t.data_ptr()
+
+
 def conv_out_len(Lin, k, s, p):
     return (Lin + 2 * p - k) // s + 1
 
@@ -463,20 +470,56 @@ def fill(t, value):
     return t
 
 
-def stft(y, n_fft, hop, polar=False, out=None, single_frame=None):
-    """(n_signals, n_samples) -> (n_signals, 2, n_fft/2, 1 + n_samples // hop); preproc_mdb.py:84-97 (+ data.py:39-47)."""
+def stft(y, n_fft, hop, polar=False, out=None, single_frame=None, chunk_start=None, chunk_row=None, chunk_len=None):
+    """(n_signals, n_samples) -> (n_signals, 2, n_fft/2, 1 + n_samples // hop); preproc_mdb.py:84-97 (+ data.py:39-47).
+
+    Chunked source (preproc_mdb.py:66-97): with ``chunk_start`` (int64 device tensor) signal s is the ``chunk_len`` samples of
+    row ``chunk_row[s]`` (int32 device tensor; default row 0) of y (rows, samples) that begin at chunk_start[s]; samples past
+    the end of the row read as zero -- no gathered or zero-padded copy of the audio is made."""
     if y.dim() == 1:
         y = y[None]
-    n_sig, n_samp = y.shape
+    a = _lib.StftArgs()
+    if chunk_start is None:
+        n_sig, n_samp = y.shape
+    else:
+        if chunk_start.dtype != torch.int64 or (chunk_row is not None and chunk_row.dtype != torch.int32):
+            raise TypeError("chunk_start must be int64 and chunk_row int32")
+        n_sig, n_samp = chunk_start.numel(), int(chunk_len)
+        if chunk_row is not None and chunk_row.numel() != n_sig:
+            raise ValueError("chunk_row needs one entry per chunk")
+        a.chunk_start = _dense_as(chunk_start, torch.int64, "chunk_start")
+        a.chunk_row = _dense_as(chunk_row, torch.int32, "chunk_row") if chunk_row is not None else None
+        a.src_len, a.src_stride = y.shape[1], y.shape[1]
     nf = 1 + n_samp // hop
     if out is None:
         out = torch.empty(n_sig, 2, n_fft // 2, nf, device=y.device, dtype=torch.float32)
-    a = _lib.StftArgs()
+    elif tuple(out.shape) != (n_sig, 2, n_fft // 2, nf):
+        raise ValueError(f"stft: out must be {(n_sig, 2, n_fft // 2, nf)}, got {tuple(out.shape)}")
     a.n_signals, a.n_samples, a.n_fft, a.hop, a.n_frames, a.polar = n_sig, n_samp, n_fft, hop, nf, int(polar)
     a.single_frame = _tls.stft_single if single_frame is None else int(bool(single_frame))
     a.y, a.out = _dense(y, "y"), _dense(out, "out")
     _lib.check(_lib.load().pg_stft(C.byref(a), _stream()), "stft")
     return out
+
+
+_moments_ws = {}
+
+
+def standardize_(x):
+    """preproc_mdb.py:182 in place on a dense float32 tensor: x = (x - x.mean()) / x.std() over the WHOLE array (population
+    std, moments reduced in double).  Returns the (mean, std) device tensor (2 doubles)."""
+    lib = _lib.load()
+    key = _ws_key(x.device)
+    ws = _moments_ws.get(key)
+    if ws is None:
+        ws = _moments_ws[key] = torch.empty(lib.pg_workspace_bytes_moments(), dtype=torch.uint8, device=x.device)
+    stats = torch.empty(2, dtype=torch.float64, device=x.device)
+    a = _lib.MomentsArgs()
+    a.n, a.x, a.stats = x.numel(), _dense(x, "x"), stats.data_ptr()
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    _lib.check(lib.pg_moments(C.byref(a), _stream()), "moments")
+    _lib.check(lib.pg_standardize(C.c_void_p(x.data_ptr()), x.numel(), C.c_void_p(stats.data_ptr()), _stream()), "standardize")
+    return stats
 
 
 def stft_frame_index(n_samples, n_fft, hop, device="cuda"):

@@ -7,8 +7,10 @@ is already-loaded mono audio at the target rate.
                  [0, a_len - t_slice // 1.3) after each -- the random starts come from a numpy Generator you pass, so a
                  run is reproducible (the reference uses the global np.random state)
   chunk + STFT   preproc_mdb.py:84-97  zero-padded tail, librosa-convention STFT, DC dropped, [re; im]: ONE pg_stft launch
-                 for all chunks of a track (chunks are gathered on the device)
-  normalise      preproc_mdb.py:182    (x - mean) / std over the WHOLE array (re and im together, population std)
+                 for all chunks of a track, reading the chunks in place (pg_stft_args.chunk_start / chunk_row: no gathered
+                 or zero-padded copy of the audio) and writing straight into the dataset array
+  normalise      preproc_mdb.py:182    (x - mean) / std over the WHOLE array (re and im together, population std):
+                 pg_moments (double accumulators, two-pass) + pg_standardize in place
   split          preproc_mdb.py:174-184 shuffled indices, first n_val clips -> val, rest -> train
 """
 import os
@@ -30,21 +32,30 @@ def chunk_starts(a_len, t_slice, n_random, rng):
     return starts
 
 
-def chunk_audio(audio, t_slice, n_fft, hop_length, n_random, rng, device=None):
-    """audio: mono float array (or (channels, samples)).  -> (n_chunks, channels, 2, n_fft/2, frames) device tensor."""
+def n_chunks(a_len, t_slice, n_random):
+    """Chunks chunk_starts yields for a track of a_len samples (preproc_mdb.py:73-80)."""
+    return len(range(0, a_len, t_slice)) * (1 + n_random)
+
+
+def chunk_audio(audio, t_slice, n_fft, hop_length, n_random, rng, device=None, out=None):
+    """audio: mono float array (or (channels, samples)).  -> (n_chunks, channels, 2, n_fft/2, frames) device tensor (``out``,
+    when given, is that tensor: a slice of the dataset array)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     a = np.asarray(audio, dtype=np.float32)
     if a.ndim == 1:
         a = a[None]
-    a_len = a.shape[1]
+    n_ch, a_len = a.shape
     starts = chunk_starts(a_len, t_slice, n_random, rng)
-    ad = torch.zeros(a.shape[0], a_len + t_slice, device=dev)            # zero tail = the reference's np.pad "constant"
-    ad[:, :a_len] = torch.from_numpy(a).to(dev)
-    idx = torch.tensor(starts, device=dev)[:, None] + torch.arange(t_slice, device=dev)[None, :]
-    chunks = ad[:, idx]                                                  # (channels, n_chunks, t_slice)
-    n_ch, n_chunks = chunks.shape[0], chunks.shape[1]
-    S = ops.stft(chunks.reshape(n_ch * n_chunks, t_slice).contiguous(), n_fft, hop_length)
-    return S.reshape(n_ch, n_chunks, *S.shape[1:]).transpose(0, 1).contiguous()
+    ad = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # signal order (chunk, channel): the layout of the dataset array, so the STFT writes it directly
+    st = torch.tensor(np.repeat(np.asarray(starts, np.int64), n_ch), device=dev)
+    rows = torch.tensor(np.tile(np.arange(n_ch, dtype=np.int32), len(starts)), device=dev)
+    bins, frames = n_fft // 2, 1 + t_slice // hop_length
+    if out is None:
+        out = torch.empty(len(starts), n_ch, 2, bins, frames, device=dev)
+    ops.stft(ad, n_fft, hop_length, out=out.view(len(starts) * n_ch, 2, bins, frames), chunk_start=st, chunk_row=rows,
+             chunk_len=t_slice)
+    return out
 
 
 def build_dataset(tracks, chunk_seconds=4.064, rsr=16000, n_fft=2048, hop_length=512, n_random=0, n_val=40, seed=0,
@@ -53,13 +64,19 @@ def build_dataset(tracks, chunk_seconds=4.064, rsr=16000, n_fft=2048, hop_length
     ``{out_dir}/{genre}_audio_{train,val}.npy`` when ``out_dir`` is given (preproc_mdb.py:195-196)."""
     rng = np.random.default_rng(seed)
     t_slice = int(chunk_seconds * rsr)
-    parts = [chunk_audio(t, t_slice, n_fft, hop_length, n_random, rng, device) for t in tracks]
-    x = torch.cat(parts)                                                 # (N, 1, 2, bins, frames)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    shaped = [np.asarray(t, np.float32).reshape(-1, np.shape(t)[-1]).shape for t in tracks]     # (channels, samples) per track
+    n_ch = shaped[0][0]
+    counts = [n_chunks(a_len, t_slice, n_random) for _, a_len in shaped]
+    x = torch.empty(sum(counts), n_ch, 2, n_fft // 2, 1 + t_slice // hop_length, device=dev)    # (N, channels, 2, bins, frames)
+    o = 0
+    for t, c in zip(tracks, counts):
+        chunk_audio(t, t_slice, n_fft, hop_length, n_random, rng, dev, out=x[o:o + c])
+        o += c
     if x.shape[1] == 1:
         x = x[:, 0]                                                      # np.squeeze(axis=1), preproc_mdb.py:179-180
-    mean = x.double().mean()
-    std = x.double().std(unbiased=False)                                 # numpy .std() is the population std
-    x = ((x - mean.float()) / std.float()).cpu().numpy().astype(np.float32)
+    ops.standardize_(x)                                                  # numpy .std() is the population std
+    x = x.cpu().numpy()
     idx = np.linspace(0, len(x) - 1, len(x), dtype=int)
     rng.shuffle(idx)
     val, train = x[idx][:n_val], x[idx][n_val:]
