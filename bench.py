@@ -284,6 +284,9 @@ def run_train(a, torch, dist, world, rank, local):
     }
     if dp is not None:
         out["dp"] = dp
+    if a.rehearse_on_one_gpu and world > 1:
+        out["rehearsal"] = True
+        out["rehearsal_note"] = f"{world} ranks share ONE GPU and all-reduce through the host (gloo): code-path check, not a measurement"
     if world == 1 and a.precision == "fp32" and not a.no_other_precisions:
         other = {}
         for mode in ("bf16x3", "bf16"):
@@ -438,6 +441,11 @@ def main():
                     help="N > 1: payload of the gradient all-reduce (bf16 halves the xGMI bytes; default fp32)")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="N = 1 only: run the data-parallel code path (bucketed RCCL all-reduce, diagnostics) on a one-rank group")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank drives cuda:0 and the process group is gloo (device tensors staged through "
+                         "the host).  Exercises the whole N > 1 code path (sharded seeds, bucketed async all-reduce from inside backward, "
+                         "barrier + max-over-ranks timing, replica checksum, dp diagnostics); the JSON line carries \"rehearsal\": true "
+                         "and its value is NOT a measurement")
     ap.add_argument("--serial-adam", action="store_true", help="A/B: one Adam launch after backward instead of per-layer slices on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true")
@@ -460,8 +468,12 @@ def main():
         sys.exit(subprocess.call(cmd))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the phasegen hot path has no CPU fallback")
+    if a.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 and a.rehearse_on_one_gpu:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     elif a.dp_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -90,3 +90,25 @@ def test_bench_contract_line_and_dp_selftest(tmp_path):
     dp = d["dp"]
     assert dp["rccl_ranks"] == 1 and dp["backend"] == "nccl" and dp["replicas_identical"] is True
     assert set(dp["allreduce_alone_ms"]) == {"U0", "U1", "U2", "U3", "D3", "D2", "D1", "D0"} and dp["step_ms_compute_only"] > 0
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), except that both
+    ranks share cuda:0 and all-reduce over gloo (--rehearse-on-one-gpu; RCCL refuses two ranks on one device): the N > 1
+    branch -- per-rank seeds, bucketed async all-reduce inside backward, barrier + MAX-over-ranks timing, the replica checksum
+    that fails the run when ranks diverge, the dp diagnostics -- runs for real, and rank 0 alone prints the line."""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--channels", "32", "--frames", "64",
+               "--batch", "4", "--steps", "2", "--warmup", "1", "--rehearse-on-one-gpu"], cwd=str(tmp_path))
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 4 * 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]        # whole-job frames / max-over-ranks time
+    dp = d["dp"]
+    assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and dp["replicas_identical"] is True
+    assert dp["allreduce_payload_bytes"] > 0 and 0.0 <= dp["comm_hidden_frac"] <= 1.0
+    assert "cpu_baseline" not in d and "other_precisions" not in d                              # N = 1 only
