@@ -173,7 +173,8 @@ def roofline_of(by, peak, step_tflops, precision, headline_shape):
 
 
 def dp_diagnostics(torch, dist, trainer, batch, world, step_ms):
-    """N > 1 only.  Fails (SystemExit) when the replicas' parameters differ after the timed steps."""
+    """N > 1 only.  When the replicas' parameters differ after the timed steps the line carries dp.error / "invalid" and the
+    process exits with status 3 after printing it."""
     from phasegen.unet import BACKWARD_ORDER
     eng = trainer.engine
     flat = eng.arena.flat
@@ -190,9 +191,10 @@ def dp_diagnostics(torch, dist, trainer, batch, world, step_ms):
     same = all(torch.equal(got[0], t) for t in got)
     out = {"rccl_ranks": int(one.item()), "backend": dist.get_backend(), "replicas_identical": bool(same),
            "param_checksum": [float(v) for v in got[0].cpu()]}
-    if not same:
-        print(json.dumps({"error": "data-parallel replicas diverged", "checksums": [[float(v) for v in t.cpu()] for t in got]}), flush=True)
-        raise SystemExit(3)
+    if not same:        # the run is INVALID: say so in the line (rank 0 still prints it) and exit non-zero after it
+        out["error"] = "data-parallel replicas diverged"
+        out["checksums"] = [[float(v) for v in t.cpu()] for t in got]
+        return out
     # (2) every bucket's all-reduce alone on an otherwise idle chip (events on the launch stream, which waits for RCCL's)
     red = trainer.reducer
     alone = {}
@@ -284,6 +286,8 @@ def run_train(a, torch, dist, world, rank, local):
     }
     if dp is not None:
         out["dp"] = dp
+    if dp is not None and not dp["replicas_identical"]:
+        out["invalid"] = "data-parallel replicas diverged: value is not a valid measurement"
     if a.rehearse_on_one_gpu and world > 1:
         out["rehearsal"] = True
         out["rehearsal_note"] = f"{world} ranks share ONE GPU and all-reduce through the host (gloo): code-path check, not a measurement"
@@ -307,6 +311,9 @@ def run_train(a, torch, dist, world, rank, local):
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(C, L, a.cpu_threads)
     print(json.dumps(out), flush=True)
+    if "invalid" in out:
+        sys.stdout.flush()
+        raise SystemExit(3)
 
 
 def run_fwd(a, torch, dist, world, rank, local):
