@@ -171,3 +171,31 @@ def test_tensor_on_another_device_is_refused_not_faulted():
         device = torch.device("cuda", torch.cuda.current_device() + 1)
     with pytest.raises(ValueError, match="current device"):
         ops._on_current_device(Fake(), "x")
+
+
+def test_integration_md_stub_is_a_working_binding():
+    """INTEGRATION.md §B shows the ctypes stub a maintainer of the reference would write against include/phasegen.h.  The
+    block is executed verbatim here (so the document cannot drift from the header) and its conv1d_fwd is compared with
+    stock fp32 torch on the CPU: nn.Conv1d(...)(LeakyReLU(0.2)(x)) of model.py:77-80."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# pg_stub\.py.*?)```", text, flags=re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                                   # the stub loads the library by its path relative to the repository root
+    try:
+        exec(compile(block, "INTEGRATION.md:pg_stub", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    import ctypes
+    assert ctypes.sizeof(ns["ConvArgs"]) == 200
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 16, 64, generator=g)
+    w = torch.randn(32, 16, 8, generator=g) * 0.1
+    got = ns["conv1d_fwd"](x.cuda(), w.cuda(), stride=2, pad=1, act=1)          # act 1 = LeakyReLU(0.2) on the input, fused
+    want = F.conv1d(F.leaky_relu(x, 0.2), w, stride=2, padding=1)
+    assert got.shape == want.shape and relmax(got, want) < 1e-5
+    with pytest.raises(RuntimeError):
+        ns["conv1d_fwd"](x.cuda(), w.cuda(), stride=2, pad=1, precision=7)         # PG_ERR_UNSUPPORTED -> RuntimeError with the message
