@@ -1,9 +1,10 @@
 """End-to-end GPU parity of the U-Net path against the committed golden fixtures (outputs of the imported
 reference, oracle/gen_golden.py) and against the oracle on fresh seeded inputs.
 
-Tolerance: BASELINE.json asks for "within 1e-4 rel fp32"; errors are measured relative to the tensor's max-abs.
-Gradients flow through six batch-norms and reductions of up to 32 768 terms, so they get 5e-4 at the small,
-ill-conditioned golden sizes (B*L' as small as 3 statistics per channel); forward tensors hold 1e-4.
+Tolerance: BASELINE.json asks for "within 1e-4 rel fp32"; errors are measured relative to the tensor's max-abs.  Measured on
+MI355X against these goldens (tools/golden_margin.py): forward tensors <= 3.0e-6, gradients <= 6.2e-6, three Adam steps
+9.4e-6 (parameters) / 2.9e-6 (exp_avg).  The bounds below are 2e-5 for forward tensors and 5e-5 for gradients and Adam
+state (round 1: 1e-4 / 5e-4 / 2e-3): tight enough that a 1e-4 systematic error in any gradient fails.
 """
 import os
 
@@ -14,7 +15,7 @@ import torch
 from phasegen import detgen
 
 pytestmark = pytest.mark.gpu
-TOL_F, TOL_G = 1e-4, 5e-4
+TOL_F, TOL_G = 2e-5, 5e-5
 CASES = [(8, 24, 1), (8, 64, 3), (16, 24, 3), (16, 128, 2), (8, 128, 3), (16, 64, 1)]
 
 
@@ -65,8 +66,8 @@ def test_forward_backward_vs_reference_golden(case, golden_dir):
 
 @pytest.mark.parametrize("case", [(16, 128, 2), (8, 64, 3)])
 def test_golden_parity_also_holds_in_bf16x3_split_mode(case, golden_dir):
-    """The reference goldens at the SAME tolerances with pg_conv_set_precision(2) (three bf16 MFMA products per fp32
-    product, ~5e-6 per conv): forward tensors 1e-4, gradients 5e-4."""
+    """The reference goldens in the bf16x3 split mode (three bf16 MFMA products per fp32 product, ~5e-6 per conv; measured
+    <= 3.5e-5 forward, <= 8.6e-5 gradients): forward tensors within the 1e-4 of BASELINE.json, gradients 3e-4."""
     from phasegen import ops
     C, L, B = case
     gold = np.load(os.path.join(golden_dir, f"unet_C{C}_L{L}_B{B}.npz"))
@@ -76,15 +77,15 @@ def test_golden_parity_also_holds_in_bf16x3_split_mode(case, golden_dir):
         eng = m.engine
         batch = torch.from_numpy(detgen.make_batch(B, C, L, seed=1)).cuda()
         out = eng.forward(batch[:, 0])
-        assert rel(out, gold["out"]) < TOL_F
+        assert rel(out, gold["out"]) < 1e-4
         for k, v in eng.intermediates().items():
-            assert rel(v, activated(gold, k)) < TOL_F, k
+            assert rel(v, activated(gold, k)) < 1e-4, k
         dpred = torch.empty_like(out)
         losses = ops.loss_fwd_bwd(out, batch, dpred)
         assert np.allclose(losses.cpu().numpy(), gold["loss"], rtol=2e-5)
         eng.backward(dpred)
         for k in detgen.param_order():
-            assert rel(eng.arena.g(k), gold["grad/" + k]) < TOL_G, k
+            assert rel(eng.arena.g(k), gold["grad/" + k]) < 3e-4, k
     finally:
         ops.set_conv_precision("fp32")
 
@@ -101,8 +102,8 @@ def test_three_adam_steps_vs_reference_golden(golden_dir):
         assert np.allclose(losses, gold["adam_losses"][s], rtol=1e-4), (s, losses, gold["adam_losses"][s])
     a = m.engine.arena
     for k in detgen.param_order():
-        assert rel(a.p(k), gold["adam3/p/" + k]) < 2e-4, k
-        assert rel(a.view(k, tr.optim.m), gold["adam3/m/" + k]) < 2e-3, k
+        assert rel(a.p(k), gold["adam3/p/" + k]) < 5e-5, k
+        assert rel(a.view(k, tr.optim.m), gold["adam3/m/" + k]) < 5e-5, k
     for k in detgen.BN_KEYS:
         assert rel(a.buffers[k + ".running_mean"], gold["adam3/stat/" + k + ".running_mean"]) < TOL_F
         assert rel(a.buffers[k + ".running_var"], gold["adam3/stat/" + k + ".running_var"]) < TOL_F
@@ -186,7 +187,7 @@ def test_full_size_forward_vs_reference_golden(golden_dir):
     x = torch.from_numpy(detgen.make_batch(1, C, L, seed=1)[:, 0]).cuda()
     out = m.engine.forward(x)
     got = out.reshape(-1)[torch.from_numpy(gold["sample_idx"]).cuda()].cpu().numpy()
-    assert np.max(np.abs(got - gold["sample_val"])) / np.max(np.abs(gold["sample_val"])) < TOL_F
+    assert np.max(np.abs(got - gold["sample_val"])) / np.max(np.abs(gold["sample_val"])) < 5e-5      # K up to 131 072 per output
     for k, v in m.engine.intermediates().items():
         if ":" in k:
             continue                   # stored pre-activated; the fixture holds statistics of the raw tensors only
