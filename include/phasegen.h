@@ -36,6 +36,7 @@ enum { PG_ACT_NONE = 0, PG_ACT_LEAKY02 = 1 /* nn.LeakyReLU(0.2), model.py:80 */,
  *   Conv1d          x (B,Cin,Lin) * w (Cout,Cin,k)  -> y (B,Cout,Lout),  Lout = (Lin + 2 pad - k)/stride + 1
  *   ConvTranspose1d x (B,Cin,Lin) * w (Cin,Cout,k)  -> y (B,Cout,Lout),  Lout = (Lin - 1) stride - 2 pad + k
  * bias is never used (model.py:65-69: use_bias == False under BatchNorm). */
+struct pg_adam_args;
 typedef struct pg_conv_args {
     int32_t B, Cin, Cout, Lin, Lout, k, stride, pad;
     const float* x;  int64_t x_bs;   /* forward input; read by *_fwd and *_wgrad                           */
@@ -59,6 +60,12 @@ typedef struct pg_conv_args {
     void* workspace; int64_t workspace_bytes; /* optional scratch (pg_workspace_bytes_conv()): lets tile counts   */
                                      /*   that quantise badly over the CUs be split evenly (stream-K);      */
                                      /*   contents are garbage between calls; NULL = always one tile per WG */
+    const struct pg_adam_args* adam; /* *_wgrad only, optional (NULL): the optimiser step of THIS weight fused into the   */
+                                     /*   wgrad epilogue (train.py:61-62 in one kernel): adam->p / m / v are the weight,   */
+                                     /*   exp_avg and exp_avg_sq tensors (layout of w), updated from the gradient value the */
+                                     /*   epilogue stores to dw -- same arithmetic as pg_adam_step, bit for bit; adam->g   */
+                                     /*   and adam->n are ignored.  Callers order the layer's dgrad (which reads w) BEFORE */
+                                     /*   this call on the stream.  Not for data-parallel runs (reduce first).             */
 } pg_conv_args;
 int64_t pg_workspace_bytes_conv(void);
 /* pg_conv_args.precision (BASELINE config 5): PG_PREC_FP32 (0, default) = fp32 operands, v_mfma_f32_32x32x2_f32, the 1e-4

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_the_header_layout():
     from phasegen import _lib
-    assert ctypes.sizeof(_lib.ConvArgs) == 8 * 4 + 8 + 8 + 4 + 4 + 8 + 4 * 16 + 8 + 8 + 8 + 8 + 24 + 16   # 200
+    assert ctypes.sizeof(_lib.ConvArgs) == 8 * 4 + 8 + 8 + 4 + 4 + 8 + 4 * 16 + 8 + 8 + 8 + 8 + 24 + 16 + 8   # 208
     assert _lib.ConvArgs.precision.offset == 52 and _lib.ConvArgs.schedule.offset == 148    # the two former pad words
     assert ctypes.sizeof(_lib.StftArgs) == 80 and ctypes.sizeof(_lib.IstftArgs) == 88
     assert ctypes.sizeof(_lib.MomentsArgs) == 40

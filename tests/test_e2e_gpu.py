@@ -190,7 +190,7 @@ def test_integration_md_stub_is_a_working_binding():
     finally:
         os.chdir(cwd)
     import ctypes
-    assert ctypes.sizeof(ns["ConvArgs"]) == 200
+    assert ctypes.sizeof(ns["ConvArgs"]) == 208
     g = torch.Generator().manual_seed(3)
     x = torch.randn(3, 16, 64, generator=g)
     w = torch.randn(32, 16, 8, generator=g) * 0.1

@@ -266,3 +266,43 @@ def test_stream_k_is_bit_identical_run_to_run_and_matches_plain_closely():
     ops.set_conv_schedule(0)
     assert torch.equal(outs[0], outs[1])
     assert relerr(outs[0], outs[2]) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("geom", GEOMS, ids=[f"{'T' if g[0] else 'C'}{g[1]}-{g[2]}-k{g[3]}s{g[4]}" for g in GEOMS])
+def test_wgrad_with_fused_adam_equals_wgrad_then_adam(geom, schedule, precision):
+    """pg_conv_args.adam: the Adam update of a conv weight in the epilogue of its wgrad kernel (GEMM kernel for whole tiles,
+    fixup kernel for stream-K split tiles; raw-window and im2col kernels; every operand precision) leaves dw, p, exp_avg and
+    exp_avg_sq BIT-identical to the plain wgrad followed by pg_adam_step -- at step 1 (zero state) and at step 3."""
+    from phasegen import ops
+    tr, Cin, Cout, k, s, p, Lin, B = geom
+    Lout = ops.convt_out_len(Lin, k, s, p) if tr else ops.conv_out_len(Lin, k, s, p)
+    wshape = (Cin, Cout, k) if tr else (Cout, Cin, k)
+    x, dy = rnd(1, B, Cin, Lin).cuda(), rnd(2, B, Cout, Lout).cuda()
+    for step, grad_scale in ((1, 1.0), (3, 0.5)):
+        w0 = rnd(3, *wshape).cuda()
+        m0 = rnd(4, *wshape).cuda() * (0.01 if step > 1 else 0.0)
+        v0 = rnd(5, *wshape).cuda().abs() * (1e-4 if step > 1 else 0.0)
+        dw_ref = torch.empty_like(w0)
+        ops.conv_wgrad(x, dy, dw_ref, s, p, x_act=1, transposed=tr, precision=precision)
+        w_ref, m_ref, v_ref = w0.clone(), m0.clone(), v0.clone()
+        ops.adam_step(w_ref.view(-1), dw_ref.view(-1), m_ref.view(-1), v_ref.view(-1), step, lr=1e-3, grad_scale=grad_scale)
+        w, m, v, dw = w0.clone(), m0.clone(), v0.clone(), torch.empty_like(w0)
+        ad = ops.adam_args(w, m, v, step, lr=1e-3, grad_scale=grad_scale)
+        ops.conv_wgrad(x, dy, dw, s, p, x_act=1, transposed=tr, precision=precision, adam=ad)
+        assert torch.equal(dw, dw_ref)
+        assert torch.equal(w, w_ref) and torch.equal(m, m_ref) and torch.equal(v, v_ref)
+        assert not torch.equal(w, w0)
+
+
+def test_fused_adam_argument_errors():
+    from phasegen import ops
+    x, dy = rnd(1, 2, 8, 24).cuda(), rnd(2, 2, 16, 12).cuda()
+    w = rnd(3, 16, 8, 4).cuda()
+    m, v, dw = torch.zeros_like(w), torch.zeros_like(w), torch.empty_like(w)
+    with pytest.raises(RuntimeError, match="1-based"):
+        ops.conv_wgrad(x, dy, dw, 2, 1, adam=ops.adam_args(w, m, v, 0))
+    with pytest.raises(RuntimeError, match="alias"):
+        ops.conv_wgrad(x, dy, dw, 2, 1, adam=ops.adam_args(dw, m, v, 1))
+    with pytest.raises(ValueError, match="shape"):
+        ops.conv_wgrad(x, dy, dw, 2, 1, adam=ops.adam_args(w[:8].contiguous(), m[:8].contiguous(), v[:8].contiguous(), 1))

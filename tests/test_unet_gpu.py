@@ -219,19 +219,26 @@ def test_optimizer_state_resume_is_exact(tmp_path):
     assert r.optim.step_count == 3
 
 
-def test_overlapped_adam_is_bit_identical_to_the_serial_update():
-    """Trainer runs each layer's slice of the Adam update on a side stream beside the rest of backward (the update is
-    HBM-bound, backward's convolutions MFMA-bound).  Elementwise arithmetic: three steps must leave parameters, Adam
-    state and losses BIT-identical to the serial schedule (backward, then one update over the whole arena)."""
+@pytest.mark.parametrize("shape", [(16, 64, 3), (40, 48, 2)])
+def test_fused_and_overlapped_adam_are_bit_identical_to_the_serial_update(shape):
+    """Three schedules of the same update (train.py:61-62): (a) FUSED -- every conv weight is updated in the epilogue of its
+    own wgrad kernel, which runs after the layer's dgrad; BatchNorm's gamma / beta by small launches (the single-GPU default);
+    (b) OVERLAPPED -- each layer's slice of a separate Adam kernel on a side stream beside the rest of backward (what a
+    data-parallel rank runs, after the bucket's all-reduce); (c) SERIAL -- backward, then one update over the whole arena.
+    Elementwise arithmetic from one definition (pg_adam_one): three steps must leave parameters, gradients, Adam state and
+    losses BIT-identical.  C = 40 makes partial tiles (Cout = 80 rows of a 128-row tile) and stream-K fixups carry the update."""
     from phasegen.trainer import Trainer
-    C, L, B = 16, 64, 3
+    C, L, B = shape
     batches = [torch.from_numpy(detgen.make_batch(B, C, L, seed=40 + i)).cuda() for i in range(3)]
-    a, b = Trainer(make_model(C), overlap_adam=True), Trainer(make_model(C), overlap_adam=False)
-    assert a.overlap_adam and not b.overlap_adam
+    a, o, b = Trainer(make_model(C)), Trainer(make_model(C), fuse_adam=False), Trainer(make_model(C), overlap_adam=False)
+    assert a.fuse_adam and o.overlap_adam and not o.fuse_adam and not b.overlap_adam and not b.fuse_adam
     for x in batches:
-        la, lb = a.step(x).clone(), b.step(x).clone()
-        assert torch.equal(la, lb)
+        la, lo, lb = a.step(x).clone(), o.step(x).clone(), b.step(x).clone()
+        assert torch.equal(la, lb) and torch.equal(lo, lb)
     torch.cuda.synchronize()
-    assert torch.equal(a.engine.arena.flat, b.engine.arena.flat)
-    assert torch.equal(a.optim.m, b.optim.m) and torch.equal(a.optim.v, b.optim.v)
-    assert a.optim.step_count == b.optim.step_count == 3
+    for t in (a, o):
+        assert torch.equal(t.engine.arena.flat, b.engine.arena.flat)
+        assert torch.equal(t.engine.arena.grad, b.engine.arena.grad)
+        assert torch.equal(t.optim.m, b.optim.m) and torch.equal(t.optim.v, b.optim.v)
+        assert t.optim.step_count == b.optim.step_count == 3
+    assert not torch.equal(b.engine.arena.flat, make_model(C).engine.arena.flat)        # the steps did move the weights

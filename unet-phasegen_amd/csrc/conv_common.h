@@ -33,6 +33,9 @@ struct IgemmParams {
     int x_pitch;
     unsigned short* yh; long yh_bs; int yh_pitch; float yh_slope;
     unsigned short* yh2; long yh2_bs; int yh2_pitch; float yh2_slope;
+    // G (wgrad) only: optional Adam update fused into the epilogue (pg_conv_args.adam): parameter / exp_avg / exp_avg_sq
+    // tensors shaped like dW, updated from the gradient value the epilogue stores.  ad_p == NULL: plain wgrad.
+    float* ad_p; float* ad_m; float* ad_v; PgAdamScalars ad;
 };
 
 }  // namespace pgconv
@@ -430,6 +433,38 @@ __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const AccT<MB, 
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (MB * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M) p.y[(long)m * Ntot + n] = acc.c[i][j][r];
+            }
+    }
+    if (!p.ad_p) return;
+    // fused Adam (28 B per parameter of a separate pass -> 24 B here): eight rows at a time -- 24 loads in flight per lane, one
+    // memory latency per half block, inside the GEMM loop's register budget (a scheduling barrier keeps the compiler from
+    // hoisting the next chunk's loads); 32-bit element offsets (operands are < 2 GiB)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * (NB * 32) + j * 32 + (lane & 31);
+        if (n >= Ntot) continue;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int mb = m0 + wm * (MB * 32) + i * 32 + 16 * q + 4 * (lane >> 5);
+                float pp[8], mm[8], vv[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    const unsigned o = (unsigned)(m < p.M ? m : 0) * (unsigned)Ntot + (unsigned)n;
+                    pp[r] = p.ad_p[o]; mm[r] = p.ad_m[o]; vv[r] = p.ad_v[o];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m >= p.M) continue;
+                    const unsigned o = (unsigned)m * (unsigned)Ntot + (unsigned)n;
+                    pg_adam_one(pp[r], acc.c[i][j][8 * q + r], mm[r], vv[r], p.ad.omb1, p.ad.b2, p.ad.omb2, p.ad.step_size, p.ad.bc2_sqrt,
+                                p.ad.eps, p.ad.gs);
+                    p.ad_p[o] = pp[r]; p.ad_m[o] = mm[r]; p.ad_v[o] = vv[r];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
     }
 }

@@ -328,6 +328,20 @@ static int run_conv1d_dgrad(const pg_conv_args* a, void* stream, char* desc, int
     return launch_t(p, kn, a->workspace_bytes, (hipStream_t)stream);
 }
 
+// pg_conv_args.adam: the optimiser step of this weight in the wgrad epilogue (whole tiles: the GEMM kernel's; split tiles: the
+// fixup kernel's -- every element of dW passes through exactly one epilogue_g)
+static int set_fused_adam(IgemmParams& p, const pg_conv_args* a) {
+    const pg_adam_args* ad = a->adam;
+    if (!ad) return PG_OK;
+    if (!ad->p || !ad->m || !ad->v) return pg_fail(PG_ERR_NULL, "wgrad: fused adam needs p, m and v");
+    if (ad->step < 1) return pg_fail(PG_ERR_SHAPE, "wgrad: fused adam: step is 1-based");
+    if (((uintptr_t)ad->p | (uintptr_t)ad->m | (uintptr_t)ad->v) & 3) return pg_fail(PG_ERR_ALIGN, "wgrad: fused adam: misaligned pointer");
+    if ((const float*)ad->p == a->dw || ad->m == a->dw || ad->v == a->dw) return pg_fail(PG_ERR_SHAPE, "wgrad: fused adam: p / m / v alias dw");
+    p.ad_p = ad->p; p.ad_m = ad->m; p.ad_v = ad->v;
+    p.ad = pg_adam_scalars(ad);
+    return PG_OK;
+}
+
 // nn.Conv1d wgrad: dw[o][c][j] = sum_{b,t} dy[b,o,t] act(x)[b,c,s*t+j-p]  -> G with P = dy (M = Cout), Q = x.
 static int run_conv1d_wgrad(const pg_conv_args* a, void* stream, char* desc, int desc_len) {
     if (int e = check_geom(a, false)) return e;
@@ -339,6 +353,7 @@ static int run_conv1d_wgrad(const pg_conv_args* a, void* stream, char* desc, int
     p.x = a->x; p.x_bs = a->x_bs; p.act_x = a->x_act; p.y = a->dw;
     p.B = a->B; p.Q = a->Cin; p.M = a->Cout; p.Lx = a->Lin; p.k = a->k; p.s = a->stride; p.p = a->pad;
     if (int e = set_extents(p, p.Q, p.Lx, p.M, p.LP)) return e;
+    if (int e = set_fused_adam(p, a)) return e;
     p.ws = (float*)a->workspace;
     return launch(KIND_G, p, kn, p.M, (long)p.Q * p.k, (long)p.B * p.LP, a->workspace_bytes, (hipStream_t)stream);
 }
@@ -354,6 +369,7 @@ static int run_convt1d_wgrad(const pg_conv_args* a, void* stream, char* desc, in
     p.x = a->dy; p.x_bs = a->dy_bs; p.act_x = PG_ACT_NONE; p.y = a->dw;
     p.B = a->B; p.Q = a->Cout; p.M = a->Cin; p.Lx = a->Lout; p.k = a->k; p.s = a->stride; p.p = a->pad;
     if (int e = set_extents(p, p.Q, p.Lx, p.M, p.LP)) return e;
+    if (int e = set_fused_adam(p, a)) return e;
     p.ws = (float*)a->workspace;
     return launch(KIND_G, p, kn, p.M, (long)p.Q * p.k, (long)p.B * p.LP, a->workspace_bytes, (hipStream_t)stream);
 }

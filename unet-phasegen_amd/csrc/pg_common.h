@@ -37,3 +37,19 @@ __device__ __forceinline__ void pg_complex_from_parts(float& re, float& im) {
     re = re + t;
     im = 0.0f + (im + 0.0f);
 }
+
+// Adam (torch.optim.Adam defaults, single-tensor path of torch 2.x): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g g;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  ONE definition, used by the streaming kernel (pointwise.hip) and by the
+// wgrad epilogue (conv_common.h), so that the fused update is bit-identical to the separate one.
+__device__ __forceinline__ void pg_adam_one(float& p, float g, float& m, float& v, float omb1, float b2, float omb2,
+                                            float step_size, float bc2_sqrt, float eps, float gs) {
+    g *= gs;
+    m = m + omb1 * (g - m);
+    v = v * b2 + omb2 * (g * g);
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+// Host-side folding of the hyper-parameters into what the kernels take.
+struct PgAdamScalars { float omb1, b2, omb2, step_size, bc2_sqrt, eps, gs; };
+struct pg_adam_args;
+PgAdamScalars pg_adam_scalars(const pg_adam_args* a);   // pointwise.hip

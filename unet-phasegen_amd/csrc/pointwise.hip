@@ -276,14 +276,6 @@ __global__ __launch_bounds__(256) void standardize_kernel(float* __restrict__ x,
 // Adam (torch.optim.Adam defaults, single-tensor path of torch 2.x): m.lerp_(g, 1-b1); v = b2 v + (1-b2) g g;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps).  28 B of HBM traffic per parameter.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float omb1, float b2, float omb2,
-                                         float step_size, float bc2_sqrt, float eps, float gs) {
-    g *= gs;
-    m = m + omb1 * (g - m);
-    v = v * b2 + omb2 * (g * g);
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p = p - step_size * (m / denom);
-}
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float omb1, float b2, float omb2,
@@ -295,14 +287,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float a = pp[k], b = mm[k], c = vv[k];
-            adam_one(a, gg[k], b, c, omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
+            pg_adam_one(a, gg[k], b, c, omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
             pp[k] = a; mm[k] = b; vv[k] = c;
         }
         reinterpret_cast<f32x4*>(p)[i] = pp; reinterpret_cast<f32x4*>(m)[i] = mm; reinterpret_cast<f32x4*>(v)[i] = vv;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long i = (n4 << 2) + threadIdx.x;
-        adam_one(p[i], g[i], m[i], v[i], omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
+        pg_adam_one(p[i], g[i], m[i], v[i], omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
     }
 }
 
@@ -322,14 +314,14 @@ void adam_thin_kernel(float* __restrict__ p, const float* __restrict__ g, float*
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             float a = pp[k], b = mm[k], c = vv[k];
-            adam_one(a, gg[k], b, c, omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
+            pg_adam_one(a, gg[k], b, c, omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
             pp[k] = a; mm[k] = b; vv[k] = c;
         }
         __builtin_nontemporal_store(pp, reinterpret_cast<f32x2*>(p) + i);
         __builtin_nontemporal_store(mm, reinterpret_cast<f32x2*>(m) + i);
         __builtin_nontemporal_store(vv, reinterpret_cast<f32x2*>(v) + i);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) adam_one(p[n - 1], g[n - 1], m[n - 1], v[n - 1], omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) pg_adam_one(p[n - 1], g[n - 1], m[n - 1], v[n - 1], omb1, b2, omb2, step_size, bc2_sqrt, eps, gs);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -510,25 +502,30 @@ extern "C" int pg_standardize(float* x, int64_t n, const double* stats, void* st
     return launch_ok("standardize launch failed");
 }
 
+// Python floats -> the fp32 scalars of the update, rounded exactly where torch rounds them (one definition for the streaming
+// kernel and the wgrad epilogue)
+PgAdamScalars pg_adam_scalars(const pg_adam_args* a) {
+    const double bc1 = 1.0 - pow(a->beta1, a->step), bc2 = 1.0 - pow(a->beta2, a->step);
+    return { (float)(1.0 - a->beta1), (float)a->beta2, (float)(1.0 - a->beta2), (float)(a->lr / bc1), (float)sqrt(bc2), (float)a->eps,
+             (float)a->grad_scale };
+}
+
 extern "C" int pg_adam_step(const pg_adam_args* a, void* stream) {
     if (!a || !a->p || !a->g || !a->m || !a->v) return pg_fail(PG_ERR_NULL, "adam: p, g, m, v required");
     if (a->n <= 0) return PG_OK;
     if (a->step < 1) return pg_fail(PG_ERR_SHAPE, "adam: step is 1-based");
     if (((uintptr_t)a->p | (uintptr_t)a->g | (uintptr_t)a->m | (uintptr_t)a->v) & 15) return pg_fail(PG_ERR_ALIGN, "adam: pointers must be 16-byte aligned");
-    const double bc1 = 1.0 - pow(a->beta1, a->step), bc2 = 1.0 - pow(a->beta2, a->step);
-    const float step_size = (float)(a->lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const PgAdamScalars h = pg_adam_scalars(a);
     long blocks = ((a->n >> 2) + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16; if (blocks < 1) blocks = 1;
     if (a->thin) {
         const long cus = pg_cu_count();
         if (blocks > cus) blocks = cus;
         hipLaunchKernelGGL(adam_thin_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v, (long)a->n,
-                           (float)(1.0 - a->beta1), (float)a->beta2, (float)(1.0 - a->beta2), step_size, bc2_sqrt, (float)a->eps,
-                           (float)a->grad_scale);
+                           h.omb1, h.b2, h.omb2, h.step_size, h.bc2_sqrt, h.eps, h.gs);
         return launch_ok("adam launch failed");
     }
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v, (long)a->n,
-                       (float)(1.0 - a->beta1), (float)a->beta2, (float)(1.0 - a->beta2), step_size, bc2_sqrt, (float)a->eps,
-                       (float)a->grad_scale);
+                       h.omb1, h.b2, h.omb2, h.step_size, h.bc2_sqrt, h.eps, h.gs);
     return launch_ok("adam launch failed");
 }
 

@@ -30,7 +30,8 @@ class ConvArgs(C.Structure):
                 ("dx_ref", C.c_void_p), ("dx_ref_bs", C.c_int64),
                 ("dx_mask", C.c_int32), ("schedule", C.c_int32),
                 ("dw", C.c_void_p), ("y_act", C.c_int32), ("y2_act", C.c_int32), ("y2", C.c_void_p), ("y2_bs", C.c_int64),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("adam", C.c_void_p)]        # const pg_adam_args*: optimiser step fused into the wgrad epilogue (or NULL)
 
 
 class BnArgs(C.Structure):

@@ -273,8 +273,19 @@ def conv_dgrad(dy, w, dx, stride, pad, transposed=False, add=None, ref=None, mas
     return dx
 
 
-def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False, precision=None, schedule=None):
-    """dw = wgrad(act(x), dy), overwriting ``dw`` (same layout as the weight)."""
+def adam_args(p, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """pg_adam_args for ``conv_wgrad(..., adam=)``: the weight ``p`` and its exp_avg / exp_avg_sq, all shaped like dw."""
+    a = _lib.AdamArgs()
+    a.n = p.numel()
+    a.p, a.m, a.v = _dense(p, "p"), _dense(m, "m"), _dense(v, "v")
+    a.lr, a.beta1, a.beta2, a.eps, a.grad_scale, a.step = lr, beta1, beta2, eps, grad_scale, step
+    return a
+
+
+def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False, precision=None, schedule=None, adam=None):
+    """dw = wgrad(act(x), dy), overwriting ``dw`` (same layout as the weight).  ``adam`` (from ``adam_args``): the Adam update
+    of this weight runs in the kernel's epilogue from the gradient it stores -- bit-identical to ``adam_step`` afterwards; the
+    caller must have enqueued every reader of the old weight (the layer's dgrad) before this call."""
     Cin, Cout, k = _geom(transposed, dw)
     B, _, Lin = x.shape
     a = _conv_args(transposed, B, Cin, Cout, Lin, k, stride, pad, x.device, precision, schedule)
@@ -284,6 +295,10 @@ def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False, precisi
     a.dy, a.dy_bs = _act3(dy, "dy")
     a.dw = _dense(dw, "dw")
     a.x_act = x_act
+    if adam is not None:
+        if adam.n != dw.numel():
+            raise ValueError("conv_wgrad: fused adam tensors must have dw's shape")
+        a.adam = C.addressof(adam)
     lib = _lib.load()
     _note_plan(a, _lib.OP_CONVT1D_WGRAD if transposed else _lib.OP_CONV1D_WGRAD)
     fn = lib.pg_convt1d_wgrad if transposed else lib.pg_conv1d_wgrad

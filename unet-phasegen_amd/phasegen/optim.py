@@ -66,6 +66,14 @@ class Adam:
         ops.adam_step(a.flat[start:end], a.grad[start:end], self.m[start:end], self.v[start:end], self.step_count,
                       self.param_groups[0]["lr"], b1, b2, self.eps, grad_scale, thin=thin)
 
+    def fused_args(self, key, grad_scale=1.0):
+        """pg_adam_args of ONE parameter for the step begun with begin_step(): handed to ``ops.conv_wgrad(adam=)`` so that the
+        update of a conv weight runs in its wgrad kernel's epilogue (same arithmetic as step_range, bit for bit)."""
+        a = self.arena
+        b1, b2 = self.betas
+        return ops.adam_args(a.p(key), a.view(key, self.m), a.view(key, self.v), self.step_count, self.param_groups[0]["lr"],
+                             b1, b2, self.eps, grad_scale)
+
     def state_dict(self):
         return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.param_groups[0]["lr"]}
 

@@ -329,18 +329,20 @@ class UNetEngine:
         return f["out"]
 
     # -- backward ----------------------------------------------------------------------------------------------
-    def backward(self, g_out, on_grads_ready=None, on_layer_done=None):
+    def backward(self, g_out, on_grads_ready=None, on_layer_done=None, fused_adam=None):
         """Gradients of all 20 parameters into the gradient arena (overwritten).  ``on_grads_ready(layer)`` is
         called right after the kernels that complete a layer's gradients (conv weight + its BatchNorm's gamma/beta)
         have been enqueued -- the data-parallel wrapper launches that bucket's all-reduce from it.  ``on_layer_done(layer)``
         is called once backward has enqueued its LAST kernel that reads the layer's parameters (the dgrad): from there on
-        the optimiser may overwrite them while the remaining layers' backward kernels run."""
+        the optimiser may overwrite them while the remaining layers' backward kernels run.  ``fused_adam(key)`` (optional)
+        returns the pg_adam_args of conv weight ``key``: its update then runs in the epilogue of that weight's wgrad kernel, which
+        is ordered after the layer's dgrad (single-GPU training; gradients are still written)."""
         if self.cur is None:
             raise RuntimeError("UNet.backward called before forward")
         with torch.cuda.device(self.device):
-            self._backward(g_out, on_grads_ready, on_layer_done)
+            self._backward(g_out, on_grads_ready, on_layer_done, fused_adam)
 
-    def _backward(self, g_out, on_grads_ready, on_layer_done=None):
+    def _backward(self, g_out, on_grads_ready, on_layer_done=None, fused_adam=None):
         plan, x0 = self.cur
         f = plan["fwd"]
         B = x0.shape[0]
@@ -357,8 +359,10 @@ class UNetEngine:
 
         def wgrad(name, x, dy, act):
             key, kind, s, p = LAYERS[name]
+            adam = fused_adam(key) if fused_adam is not None else None       # kept alive until the call has returned
             with ops.timed(name + ".wgrad"):
-                ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"), precision=self.precision, schedule=sched)
+                ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"), precision=self.precision, schedule=sched,
+                               adam=adam)
 
         def dgrad(name, dy, dx, **kw):
             key, kind, s, p = LAYERS[name]
@@ -373,6 +377,22 @@ class UNetEngine:
             if on_layer_done is not None:
                 on_layer_done(name)
 
+        def layer(name, wg, dg=None, **dkw):
+            """One layer's two gradient kernels.  Plain: wgrad first, so that a data-parallel caller can start the bucket's
+            all-reduce (``ready``) under the dgrad.  With the optimiser step fused into the wgrad epilogue the dgrad -- the last
+            reader of the old weight -- must come first."""
+            if fused_adam is None:
+                wgrad(name, *wg)
+                ready(name)
+                if dg is not None:
+                    dgrad(name, *dg, **dkw)
+            else:
+                if dg is not None:
+                    dgrad(name, *dg, **dkw)
+                wgrad(name, *wg)
+                ready(name)
+            done(name)
+
         # up path, outermost first.  Operands are the stored activated tensors (identity on load); the mask relu'(.) is
         # taken from their sign.
         for name, cat, raw, gin, g_raw, g_cat in (("U0", "cat0", "r0", g_out, "g_r0", "g_cat0"),
@@ -380,28 +400,14 @@ class UNetEngine:
                                                   ("U2", "cat2", "r2", g["g_cat1"][:, h:], "g_r2", "g_cat2"),
                                                   ("U3", "d3", "r3", g["g_cat2"][:, h:], "g_r3", "g_d3")):
             bn_bwd(name, f[raw], gin, g[g_raw])
-            wgrad(name, f[cat], g[g_raw], ACT_NONE)
-            ready(name)
-            dgrad(name, g[g_raw], g[g_cat], ref=f[cat], mask=ACT_RELU)
-            done(name)
+            layer(name, (f[cat], g[g_raw], ACT_NONE), (g[g_raw], g[g_cat]), ref=f[cat], mask=ACT_RELU)
         # down path, innermost first; each dgrad adds the skip gradient and applies leaky' (sign of the stored leaky(h))
-        wgrad("D3", f["l2"], g["g_d3"], ACT_NONE)
-        ready("D3")
-        dgrad("D3", g["g_d3"], g["g_cat2"][:, :h], add=g["g_cat2"][:, :h], ref=f["l2"], mask=ACT_LEAKY)
-        done("D3")
+        layer("D3", (f["l2"], g["g_d3"], ACT_NONE), (g["g_d3"], g["g_cat2"][:, :h]), add=g["g_cat2"][:, :h], ref=f["l2"], mask=ACT_LEAKY)
         bn_bwd("D2", f["c2"], g["g_cat2"][:, :h], g["g_c2"])
-        wgrad("D2", f["l1"], g["g_c2"], ACT_NONE)
-        ready("D2")
-        dgrad("D2", g["g_c2"], g["g_cat1"][:, :h], add=g["g_cat1"][:, :h], ref=f["l1"], mask=ACT_LEAKY)
-        done("D2")
+        layer("D2", (f["l1"], g["g_c2"], ACT_NONE), (g["g_c2"], g["g_cat1"][:, :h]), add=g["g_cat1"][:, :h], ref=f["l1"], mask=ACT_LEAKY)
         bn_bwd("D1", f["c1"], g["g_cat1"][:, :h], g["g_c1"])
-        wgrad("D1", f["l0"], g["g_c1"], ACT_NONE)
-        ready("D1")
-        dgrad("D1", g["g_c1"], g["g_cat0"][:, :h], add=g["g_cat0"][:, :h], ref=f["l0"], mask=ACT_LEAKY)
-        done("D1")
-        wgrad("D0", x0, g["g_cat0"][:, :h], ACT_NONE)      # network input needs no dgrad
-        ready("D0")
-        done("D0")
+        layer("D1", (f["l0"], g["g_c1"], ACT_NONE), (g["g_c1"], g["g_cat0"][:, :h]), add=g["g_cat0"][:, :h], ref=f["l0"], mask=ACT_LEAKY)
+        layer("D0", (x0, g["g_cat0"][:, :h], ACT_NONE))      # network input needs no dgrad
 
     def layer_param_keys(self, name):
         keys = [LAYERS[name][0]]
