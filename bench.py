@@ -242,7 +242,7 @@ def run_train(a, torch, dist, world, rank, local):
     model = UNetModel(C, 2 * C, gpu_ids=[local], precision=a.precision)
     selftest = a.dp_selftest and world == 1         # one-rank RCCL group: every collective of the N > 1 path is really issued
     trainer = Trainer(model, lr=1e-3, grad_compress=None if a.grad_compress == "none" else a.grad_compress, always_reduce=selftest,
-                      overlap_adam=not a.serial_adam)
+                      overlap_adam=not a.serial_adam, fuse_adam=not a.no_fused_adam)
     batch = synthetic_batch(torch, B, C, L, 1 + rank)
 
     def sync():
@@ -280,6 +280,8 @@ def run_train(a, torch, dist, world, rank, local):
                                f"UNetModel({C}, {2 * C}), per-GPU batch {B} x {C} bins x {L} frames (BASELINE configs[2]{'/[3]' if world > 1 else ''})",
                    "global_batch": world * B, "frames": L, "channels": C, "parallelism": f"dp{world}",
                    "grad_allreduce_payload": "fp32" if a.grad_compress == "none" else a.grad_compress,
+                   "adam": ("fused into the wgrad epilogues" if trainer.fuse_adam else
+                            ("per-layer slices on a side stream" if trainer.overlap_adam else "one launch after backward")),
                    "final_loss": loss_val},
         "roofline": roofline_of(by, peak, step_flops / (dt / a.steps) / 1e12, a.precision, (C, L, B) == (1024, 256, 64)),
         "kernels": ks,
@@ -453,6 +455,9 @@ def main():
                          "the host).  Exercises the whole N > 1 code path (sharded seeds, bucketed async all-reduce from inside backward, "
                          "barrier + max-over-ranks timing, replica checksum, dp diagnostics); the JSON line carries \"rehearsal\": true "
                          "and its value is NOT a measurement")
+    ap.add_argument("--no-fused-adam", action="store_true",
+                    help="A/B: N = 1 runs the Adam update of every conv weight inside its wgrad kernel's epilogue; this flag falls back to "
+                         "per-layer slices of a separate Adam kernel on a side stream (what N > 1 ranks always run)")
     ap.add_argument("--serial-adam", action="store_true", help="A/B: one Adam launch after backward instead of per-layer slices on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true")
