@@ -269,6 +269,14 @@ def run_train(a, torch, dist, world, rank, local):
     fl = conv_flops(C, L, B)
     step_flops = 3 * sum(fl.values()) - fl["D0"]
     ks, by = kernel_pass(torch, ops, lambda: trainer.step(batch), 3, fl, peak, step_ms)
+    plain = None
+    if trainer.fuse_adam:
+        # the wgrad launches above carry the Adam update of their weight (24 B of HBM traffic per parameter in the epilogue, not
+        # counted in `achieved`'s flops): time the same kernels once more WITHOUT it, so the line shows both
+        trainer.fuse_adam = False
+        trainer.step(batch)
+        _, plain = kernel_pass(torch, ops, lambda: trainer.step(batch), 3, fl, peak, step_ms)
+        trainer.fuse_adam = True
     if rank != 0:
         return
     frames = world * B * L * a.steps
@@ -286,6 +294,16 @@ def run_train(a, torch, dist, world, rank, local):
         "roofline": roofline_of(by, peak, step_flops / (dt / a.steps) / 1e12, a.precision, (C, L, B) == (1024, 256, 64)),
         "kernels": ks,
     }
+    if plain is not None:
+        dom = out["roofline"]["kernel"].split(" (")[0]
+        if dom in plain:
+            nparam = {"D0": 2 * C * C * 32, "U0": 4 * C * 2 * C * 32}
+            out["roofline"]["fused_update"] = {
+                "what": "this kernel's launches also apply Adam to the weight they produce the gradient of (pg_conv_args.adam): "
+                        "24 B of HBM traffic per parameter in the epilogue, inside the measured duration, outside `achieved`'s flops",
+                "without_it": {"achieved": plain[dom]["tflops"], "frac": plain[dom]["frac"], "ms_per_step_in_kernel": plain[dom]["ms_per_step"]},
+                "adam_bytes_per_step_in_kernel": sum(24 * nparam.get(l.split(".")[0], 0) for l in by[dom]["layers"]),
+            }
     if dp is not None:
         out["dp"] = dp
     if dp is not None and not dp["replicas_identical"]:
