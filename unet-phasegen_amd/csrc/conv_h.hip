@@ -107,12 +107,20 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc.c[i][j][q] = 0.f;
 
+// Ablation hooks for dev builds (tools/abl/build_habl.sh, -DPG_HABL=n; the product build compiles them away): 1 no weight-fragment
+// reads, 2 no window reads, 3 no gathers, 4 no MFMAs, 5 = 1 + 2, 6 = 1 + 2 + 3 (pure MFMA), 7 every slab gathers slab 0 (a cache-
+// resident source), 8 weight gathers only, 9 window gathers only, 10 windows always of slab 0, 11 weights always of slab 0.
+#ifndef PG_HABL
+#define PG_HABL 0
+#endif
 #define H_ISSUE(STAGE_PTR, SLAB)                                                                              \
     {   float* const As = (STAGE_PTR) + wv * 64; float* const Bw = (STAGE_PTR) + TA + wv * 64;               \
-        const int k0 = (SLAB) * KB;                                                                          \
-        if (k0 < Ktot) {                                                                                     \
-            _Pragma("unroll") for (int e = 0; e < 2; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], k0 * 2); \
-            const int q0 = k0 / KWP;                                                                         \
+        const int k0 = PG_HABL == 7 ? ((SLAB) < p.nslab ? 0 : Ktot) : (SLAB) * KB;                           \
+        if (k0 < Ktot && PG_HABL != 3 && PG_HABL != 6) {                                                     \
+            if (PG_HABL != 9)                                                                                \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], (PG_HABL == 11 ? 0 : k0) * 2); \
+            const int q0 = (PG_HABL == 10 ? 0 : k0) / KWP;                                                   \
+            if (PG_HABL != 8)                                                                                \
             _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                              \
                 const int sq = (q0 + qi) * p.x_pitch * 2 + (KWP > 32 ? 0 : 0);                               \
                 _Pragma("unroll") for (int e = 0; e < NPC; ++e)                                              \
@@ -131,9 +139,11 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
                 _Pragma("unroll") for (int s = 0; s < 2; ++s) {      /* MFMA k-steps: k = 16 s + 8 h + (0 .. 7) */ \
                     s16x8 a[MBW], b[NBW];                                                                    \
                     _Pragma("unroll") for (int i = 0; i < MBW; ++i)                                          \
-                        a[i] = __builtin_bit_cast(s16x8, *reinterpret_cast<const f32x4*>(ap + i * 32 * 16 + (((2 * s + h) ^ sw) << 2))); \
+                        if (PG_HABL == 1 || PG_HABL == 5 || PG_HABL == 6) a[i] = (s16x8)(short)(lane + i);   \
+                        else a[i] = __builtin_bit_cast(s16x8, *reinterpret_cast<const f32x4*>(ap + i * 32 * 16 + (((2 * s + h) ^ sw) << 2))); \
                     _Pragma("unroll") for (int jb = 0; jb < NBW; ++jb) {                                     \
                         unsigned o[4];                                                                       \
+                        if (PG_HABL == 2 || PG_HABL == 5 || PG_HABL == 6) { o[0] = o[1] = o[2] = o[3] = 0x3f803f80u + lane; } else \
                         if (TJ >= 8) {                                                                       \
                             /* channel / first tap of this lane's 8 k:  TJ 32: (0, 16 s + 8 h)  16: (s, 8 h)  8: (2 s + h, 0) */ \
                             const int qi = TJ == 32 ? 0 : (TJ == 16 ? s : 2 * s + h);                        \
@@ -156,7 +166,8 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
                     }                                                                                        \
                     _Pragma("unroll") for (int i = 0; i < MBW; ++i)                                          \
                         _Pragma("unroll") for (int jb = 0; jb < NBW; ++jb)                                   \
-                            acc.c[i][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[jb]), acc.c[i][jb], 0, 0, 0); \
+                            if (PG_HABL == 4) acc.c[i][jb][0] += (float)(a[i][0] ^ b[jb][0]);                \
+                            else acc.c[i][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[jb]), acc.c[i][jb], 0, 0, 0); \
                 }                                                                                            \
             }
 
