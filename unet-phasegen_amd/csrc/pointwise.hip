@@ -59,41 +59,88 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const pg_bn_args a) {
     }
 }
 
-// Register-resident variants (every shape of the U-Net: frames <= 256, batch <= 64): the channel's B x L values are read from
-// HBM ONCE into registers -- thread t owns frame t % LR of samples t / LR, t / LR + G, ... (LR = frames rounded up to a power
-// of two, G = 256 / LR sample groups: coalesced rows, no integer division) -- and mean, variance and the normalised /
-// activated outputs are all computed from there: 1 read + 1-2 writes instead of 3 reads.  Same two-pass arithmetic
-// (mean first, then the centred squares), block sums in a fixed order.
-template <int EPT>
-__global__ __launch_bounds__(256) void bn_fwd_reg_kernel(const pg_bn_args a, int lr_shift) {
+// Register-resident variants (every shape of the U-Net: B * L <= 64 * 256): the channel's B x L values are read from HBM ONCE
+// into registers and mean, variance and the normalised / activated outputs are all computed from there: 1 read + 1-2 writes
+// instead of 3 reads.  The channel is walked FLAT: unit e = tid + 256 i of the B * L / VEC units (VEC = 4: float4 units when
+// frames and strides allow 16-byte accesses -- one wave instruction moves 1 KB --, else single floats), (sample, position)
+// advanced incrementally (no division in the loop), so every lane works whatever L is (129 frames used to idle 127 of 256
+// lanes of a power-of-two row map).  Same two-pass arithmetic (mean first, then the centred squares), block sums in a fixed
+// order: bit-reproducible.
+typedef float bnf4 __attribute__((ext_vector_type(4)));
+template <int VEC> struct BnVec;
+template <> struct BnVec<1> { typedef float T; };
+template <> struct BnVec<4> { typedef bnf4 T; };
+typedef float bnf2 __attribute__((ext_vector_type(2)));
+template <> struct BnVec<2> { typedef bnf2 T; };
+template <int VEC> __device__ __forceinline__ float bn_lane(const typename BnVec<VEC>::T& v, int k);
+template <> __device__ __forceinline__ float bn_lane<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float bn_lane<4>(const bnf4& v, int k) { return v[k]; }
+template <> __device__ __forceinline__ float bn_lane<2>(const bnf2& v, int k) { return v[k]; }
+
+struct BnWalk { int b, u, db, du, Lu; };
+__device__ __forceinline__ BnWalk bn_walk(int L, int vec) {
+    BnWalk w; w.Lu = L / vec;
+    w.b = threadIdx.x / w.Lu; w.u = threadIdx.x - w.b * w.Lu;
+    w.db = 256 / w.Lu; w.du = 256 - w.db * w.Lu;
+    return w;
+}
+__device__ __forceinline__ void bn_next(BnWalk& w) {
+    w.u += w.du; w.b += w.db;
+    if (w.u >= w.Lu) { w.u -= w.Lu; w.b += 1; }
+}
+
+// all outputs of a BatchNorm forward for VEC consecutive elements starting at (b, c, l)
+template <int VEC>
+__device__ __forceinline__ void bn_store_v(const pg_bn_args& a, int b, int c, int l, const float* o) {
+    if (VEC != 4) { for (int k = 0; k < VEC; ++k) bn_store(a, b, c, l + k, o[k]); return; }
+    if (a.y) { const float s1 = bn_slope(a.y_act); bnf4 t; for (int k = 0; k < 4; ++k) t[k] = fmaxf(o[k], s1 * o[k]); *(bnf4*)(a.y + (long)b * a.y_bs + (long)c * a.L + l) = t; }
+    if (a.y2) { const float s2 = bn_slope(a.y2_act); bnf4 t; for (int k = 0; k < 4; ++k) t[k] = fmaxf(o[k], s2 * o[k]); *(bnf4*)(a.y2 + (long)b * a.y2_bs + (long)c * a.L + l) = t; }
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    if (a.yh) { const float s3 = bn_slope(a.yh_act); us4 t; for (int k = 0; k < 4; ++k) t[k] = to_bf16_bits(fmaxf(o[k], s3 * o[k])); *(us4*)(a.yh + (long)b * a.yh_bs + (long)c * a.yh_pitch + l) = t; }
+    if (a.yh2) { const float s4 = bn_slope(a.yh2_act); us4 t; for (int k = 0; k < 4; ++k) t[k] = to_bf16_bits(fmaxf(o[k], s4 * o[k])); *(us4*)(a.yh2 + (long)b * a.yh2_bs + (long)c * a.yh2_pitch + l) = t; }
+}
+
+// The walk runs ONCE: unit i's (sample, position) is kept packed in one register (pk = b << 16 | u, -1 = past the end) and the
+// later passes decode it -- re-walking made the compiler keep every intermediate of three identical walks alive.
+template <int UPT, int VEC>          // UPT units of VEC floats per thread
+__global__ __launch_bounds__(256) void bn_fwd_reg_kernel(const pg_bn_args a) {
+    typedef typename BnVec<VEC>::T V;
     __shared__ float scratch[16];
     const int c = blockIdx.x, n = a.B * a.L;
-    const int l = threadIdx.x & ((1 << lr_shift) - 1), g = threadIdx.x >> lr_shift, G = 256 >> lr_shift;
-    const bool lok = l < a.L;
-    const float* xc = a.x + (long)c * a.L + l;
-    float v[EPT];
+    const float* xc = a.x + (long)c * a.L;
+    V v[UPT];
+    int pk[UPT];
     float s = 0.f;
+    BnWalk w = bn_walk(a.L, VEC);
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const int b = g + i * G;
-        v[i] = (lok && b < a.B) ? xc[(long)b * a.x_bs] : 0.f;
-        s += v[i];
+    for (int i = 0; i < UPT; ++i) {
+        pk[i] = w.b < a.B ? (w.b << 16) | w.u : -1;
+        if (pk[i] >= 0) {
+            v[i] = *(const V*)(xc + (long)w.b * a.x_bs + VEC * w.u);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s += bn_lane<VEC>(v[i], k);
+        }
+        bn_next(w);
     }
     const float mean = pg_block_sum(s, scratch) / (float)n;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const float d = (lok && g + i * G < a.B) ? v[i] - mean : 0.f;
-        q += d * d;
-    }
+    for (int i = 0; i < UPT; ++i)
+        if (pk[i] >= 0) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { const float d = bn_lane<VEC>(v[i], k) - mean; q += d * d; }
+        }
     const float var = pg_block_sum(q, scratch) / (float)n;
     const float invstd = 1.0f / sqrtf(var + a.eps);
     const float ga = a.gamma[c], be = a.beta[c];
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const int b = g + i * G;
-        if (lok && b < a.B) bn_store(a, b, c, l, (v[i] - mean) * invstd * ga + be);
-    }
+    for (int i = 0; i < UPT; ++i)
+        if (pk[i] >= 0) {
+            float o[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = (bn_lane<VEC>(v[i], k) - mean) * invstd * ga + be;
+            bn_store_v<VEC>(a, pk[i] >> 16, c, VEC * (pk[i] & 0xffff), o);
+        }
     if (threadIdx.x == 0) {
         a.save_mean[c] = mean;
         a.save_invstd[c] = invstd;
@@ -105,35 +152,37 @@ __global__ __launch_bounds__(256) void bn_fwd_reg_kernel(const pg_bn_args a, int
     }
 }
 
-template <int EPT>
-__global__ __launch_bounds__(256) void bn_bwd_reg_kernel(const pg_bn_args a, int lr_shift) {
+template <int UPT, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reg_kernel(const pg_bn_args a) {
+    typedef typename BnVec<VEC>::T V;
     __shared__ float scratch[16];
     const int c = blockIdx.x, n = a.B * a.L;
-    const int l = threadIdx.x & ((1 << lr_shift) - 1), g = threadIdx.x >> lr_shift, G = 256 >> lr_shift;
-    const bool lok = l < a.L;
-    const float* xc = a.x + (long)c * a.L + l;
-    const float* dyc = a.dy + (long)c * a.L + l;
+    const float* xc = a.x + (long)c * a.L;
+    const float* dyc = a.dy + (long)c * a.L;
     const float mean = a.save_mean[c], invstd = a.save_invstd[c];
-    float xh[EPT], dy[EPT];
+    V xh[UPT], dy[UPT];
+    int pk[UPT];
     float s1 = 0.f, s2 = 0.f;
+    BnWalk w = bn_walk(a.L, VEC);
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const int b = g + i * G;
-        const bool ok = lok && b < a.B;
-        dy[i] = ok ? dyc[(long)b * a.dy_bs] : 0.f;
-        xh[i] = ok ? (xc[(long)b * a.x_bs] - mean) * invstd : 0.f;
-        s1 += dy[i];
-        s2 += dy[i] * xh[i];
+    for (int i = 0; i < UPT; ++i) {
+        pk[i] = w.b < a.B ? (w.b << 16) | w.u : -1;
+        if (pk[i] >= 0) {
+            dy[i] = *(const V*)(dyc + (long)w.b * a.dy_bs + VEC * w.u);
+            const V xv = *(const V*)(xc + (long)w.b * a.x_bs + VEC * w.u);
+            xh[i] = (xv - mean) * invstd;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { s1 += bn_lane<VEC>(dy[i], k); s2 += bn_lane<VEC>(dy[i], k) * bn_lane<VEC>(xh[i], k); }
+        }
+        bn_next(w);
     }
     const float sum_dy = pg_block_sum(s1, scratch);
     const float sum_dy_xhat = pg_block_sum(s2, scratch);
-    const float k = a.gamma[c] * invstd, m1 = sum_dy / (float)n, m2 = sum_dy_xhat / (float)n;
-    float* dxc = a.dx + (long)c * a.L + l;
+    const float kk = a.gamma[c] * invstd, m1 = sum_dy / (float)n, m2 = sum_dy_xhat / (float)n;
+    float* dxc = a.dx + (long)c * a.L;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const int b = g + i * G;
-        if (lok && b < a.B) dxc[(long)b * a.dx_bs] = k * (dy[i] - m1 - xh[i] * m2);
-    }
+    for (int i = 0; i < UPT; ++i)
+        if (pk[i] >= 0) *(V*)(dxc + (long)(pk[i] >> 16) * a.dx_bs + VEC * (pk[i] & 0xffff)) = kk * (dy[i] - m1 - xh[i] * m2);
     if (threadIdx.x == 0) {
         a.dgamma[c] = sum_dy_xhat;
         a.dbeta[c] = sum_dy;
@@ -401,14 +450,33 @@ int bn_check(const pg_bn_args* a) {
     return PG_OK;
 }
 
-// register-resident BN: frames fit one workgroup row (<= 256) and each thread's share of the batch fits 64 registers
-bool bn_reg_plan(const pg_bn_args* a, int& lr_shift, int& ept) {
-    if (a->L > 256) return false;
-    lr_shift = 0;
-    while ((1 << lr_shift) < a->L) ++lr_shift;
-    const int G = 256 >> lr_shift;
-    ept = (a->B + G - 1) / G;
-    return ept <= 64;
+// register-resident BN: the channel's B * L values fit 64 registers per thread; 16-byte units where every tensor allows them
+bool bn_reg_plan(const pg_bn_args* a, bool bwd, int& vec, int& upt) {
+    const long n = (long)a->B * a->L;
+    if (n > 64L * 256) return false;
+    auto ok16 = [](const void* p, long bs) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (bs & 3) == 0); };
+    auto ok8 = [](const void* p, long bs, int pitch) { return p == nullptr || ((((uintptr_t)p) & 7) == 0 && (bs & 3) == 0 && (pitch & 3) == 0); };
+    bool v4 = (a->L & 3) == 0 && ok16(a->x, a->x_bs);
+    if (bwd) v4 = v4 && ok16(a->dy, a->dy_bs) && ok16(a->dx, a->dx_bs);
+    else v4 = v4 && ok16(a->y, a->y_bs) && ok16(a->y2, a->y2_bs) && ok8(a->yh, a->yh_bs, a->yh_pitch) && ok8(a->yh2, a->yh2_bs, a->yh2_pitch);
+    auto ok8f = [](const void* p, long bs) { return p == nullptr || ((((uintptr_t)p) & 7) == 0 && (bs & 1) == 0); };
+    bool v2 = (a->L & 1) == 0 && ok8f(a->x, a->x_bs);
+    if (bwd) v2 = v2 && ok8f(a->dy, a->dy_bs) && ok8f(a->dx, a->dx_bs);      // (forward stores of a float2 unit are scalar)
+    vec = v4 ? 4 : (v2 ? 2 : 1);
+    const long units = n / vec;
+    upt = (int)((units + 255) / 256);
+    return true;
+}
+
+template <bool BWD>
+void bn_launch_reg(const pg_bn_args* a, int vec, int upt, hipStream_t st) {
+#define PG_BN_LAUNCH(U, V) { if (BWD) hipLaunchKernelGGL((bn_bwd_reg_kernel<U, V>), dim3(a->C), dim3(256), 0, st, *a); \
+                             else hipLaunchKernelGGL((bn_fwd_reg_kernel<U, V>), dim3(a->C), dim3(256), 0, st, *a); }
+    // (units-per-thread values are the ones hipcc allocates sanely: <8, 4> and <16, 2> take 180-245 VGPRs and spill)
+    if (vec == 4) { if (upt <= 4) PG_BN_LAUNCH(4, 4) else PG_BN_LAUNCH(16, 4) }
+    else if (vec == 2) { PG_BN_LAUNCH(32, 2) }
+    else { if (upt <= 16) PG_BN_LAUNCH(16, 1) else if (upt <= 33) PG_BN_LAUNCH(33, 1) else PG_BN_LAUNCH(64, 1) }
+#undef PG_BN_LAUNCH
 }
 
 }  // namespace
@@ -443,11 +511,9 @@ extern "C" int pg_bn_fwd(const pg_bn_args* a, void* stream) {
     if (!a->x || (!a->y && !a->yh) || !a->gamma || !a->beta || !a->save_mean || !a->save_invstd)
         return pg_fail(PG_ERR_NULL, "bn_fwd: x, y (or yh), gamma, beta, save_mean, save_invstd required");
     if ((a->yh && a->yh_pitch < a->L) || (a->yh2 && a->yh2_pitch < a->L)) return pg_fail(PG_ERR_SHAPE, "bn_fwd: bf16 output pitch below L");
-    int sh, ept;
-    if (bn_reg_plan(a, sh, ept)) {
-        if (ept <= 16) hipLaunchKernelGGL(bn_fwd_reg_kernel<16>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a, sh);
-        else hipLaunchKernelGGL(bn_fwd_reg_kernel<64>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a, sh);
-    } else hipLaunchKernelGGL(bn_fwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
+    int vec, upt;
+    if (bn_reg_plan(a, false, vec, upt)) bn_launch_reg<false>(a, vec, upt, (hipStream_t)stream);
+    else hipLaunchKernelGGL(bn_fwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
     return launch_ok("bn_fwd launch failed");
 }
 
@@ -455,11 +521,9 @@ extern "C" int pg_bn_bwd(const pg_bn_args* a, void* stream) {
     if (int e = bn_check(a)) return e;
     if (!a->x || !a->dy || !a->dx || !a->gamma || !a->save_mean || !a->save_invstd || !a->dgamma || !a->dbeta)
         return pg_fail(PG_ERR_NULL, "bn_bwd: x, dy, dx, gamma, save_mean, save_invstd, dgamma, dbeta required");
-    int sh, ept;
-    if (bn_reg_plan(a, sh, ept)) {
-        if (ept <= 16) hipLaunchKernelGGL(bn_bwd_reg_kernel<16>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a, sh);
-        else hipLaunchKernelGGL(bn_bwd_reg_kernel<64>, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a, sh);
-    } else hipLaunchKernelGGL(bn_bwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
+    int vec, upt;
+    if (bn_reg_plan(a, true, vec, upt)) bn_launch_reg<true>(a, vec, upt, (hipStream_t)stream);
+    else hipLaunchKernelGGL(bn_bwd_kernel, dim3(a->C), dim3(256), 0, (hipStream_t)stream, *a);
     return launch_ok("bn_bwd launch failed");
 }
 
