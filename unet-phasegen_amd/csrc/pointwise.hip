@@ -114,12 +114,12 @@ __global__ __launch_bounds__(256) void bn_fwd_reg_kernel(const pg_bn_args a) {
     BnWalk w = bn_walk(a.L, VEC);
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
-        pk[i] = w.b < a.B ? (w.b << 16) | w.u : -1;
-        if (pk[i] >= 0) {
-            v[i] = *(const V*)(xc + (long)w.b * a.x_bs + VEC * w.u);
+        const bool ok = w.b < a.B;
+        pk[i] = ok ? (w.b << 16) | w.u : -1;
+        v[i] = *(const V*)(xc + (ok ? (long)w.b * a.x_bs + VEC * w.u : 0L));      // branch-free: all loads issue back to back
+        if (!ok) v[i] = V(0.f);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) s += bn_lane<VEC>(v[i], k);
-        }
+        for (int k = 0; k < VEC; ++k) s += bn_lane<VEC>(v[i], k);
         bn_next(w);
     }
     const float mean = pg_block_sum(s, scratch) / (float)n;
@@ -166,14 +166,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reg_kernel(const pg_bn_args a) {
     BnWalk w = bn_walk(a.L, VEC);
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
-        pk[i] = w.b < a.B ? (w.b << 16) | w.u : -1;
-        if (pk[i] >= 0) {
-            dy[i] = *(const V*)(dyc + (long)w.b * a.dy_bs + VEC * w.u);
-            const V xv = *(const V*)(xc + (long)w.b * a.x_bs + VEC * w.u);
-            xh[i] = (xv - mean) * invstd;
+        const bool ok = w.b < a.B;
+        pk[i] = ok ? (w.b << 16) | w.u : -1;
+        dy[i] = *(const V*)(dyc + (ok ? (long)w.b * a.dy_bs + VEC * w.u : 0L));   // branch-free: all loads issue back to back
+        const V xv = *(const V*)(xc + (ok ? (long)w.b * a.x_bs + VEC * w.u : 0L));
+        xh[i] = (xv - mean) * invstd;
+        if (!ok) { dy[i] = V(0.f); xh[i] = V(0.f); }
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) { s1 += bn_lane<VEC>(dy[i], k); s2 += bn_lane<VEC>(dy[i], k) * bn_lane<VEC>(xh[i], k); }
-        }
+        for (int k = 0; k < VEC; ++k) { s1 += bn_lane<VEC>(dy[i], k); s2 += bn_lane<VEC>(dy[i], k) * bn_lane<VEC>(xh[i], k); }
         bn_next(w);
     }
     const float sum_dy = pg_block_sum(s1, scratch);
