@@ -49,7 +49,8 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = WN == 2 ? wv >> 1 : (WN == 4 ? 0 : wv), wn = WN == 2 ? wv & 1 : (WN == 4 ? wv : 0);
     static_assert(MB * NB * 16 == ACC_REGS, "8 blocks per wave tile: the host launches 8 workgroups per tile");
-    const int tile = blockIdx.x / (MB * NB), blk = blockIdx.x - tile * (MB * NB), bi = blk / NB, bj = blk - bi * NB;
+    // hybrid split: tiles below p.whole were computed whole by one workgroup each -- the grid covers the split tiles only
+    const int tile = p.whole + blockIdx.x / (MB * NB), blk = blockIdx.x % (MB * NB), bi = blk / NB, bj = blk - bi * NB;
     const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, G, p.whole);
     const int first = tile * p.nslab, last = first + p.nslab - 1;
     const int g0 = split_owner(sp, first), g1 = split_owner(sp, last);
@@ -201,18 +202,18 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     else e = pgconv::launch_im2col(kind, p, grid, st, kn.prec);
     if (e == hipSuccess && split) {
         if (tall) {
-            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
-            else if (p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
-            else hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4, 1>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
+            else if (p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
+            else hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
         } else if (raw) {
-            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
-            else if (kind == KIND_T && p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
-            else if (kind == KIND_T) hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
-            else hipLaunchKernelGGL((conv_fixup_kernel<2, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
+            else if (kind == KIND_T && p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
+            else if (kind == KIND_T) hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
+            else hipLaunchKernelGGL((conv_fixup_kernel<2, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
         } else switch (kind) {
-            case KIND_F: hipLaunchKernelGGL((conv_fixup_kernel<0, WMB, 2>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid); break;
-            case KIND_T: hipLaunchKernelGGL((conv_fixup_kernel<1, WMB, 2>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid); break;
-            case KIND_G: hipLaunchKernelGGL((conv_fixup_kernel<2, WMB, 2>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid); break;
+            case KIND_F: hipLaunchKernelGGL((conv_fixup_kernel<0, WMB, 2>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid); break;
+            case KIND_T: hipLaunchKernelGGL((conv_fixup_kernel<1, WMB, 2>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid); break;
+            case KIND_G: hipLaunchKernelGGL((conv_fixup_kernel<2, WMB, 2>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid); break;
         }
         e = hipGetLastError();
     }
@@ -449,8 +450,8 @@ static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query) {
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = pgconv::launch_h(kind, p, grid, st);
     if (e == hipSuccess && split) {
-        if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 4, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
-        else hipLaunchKernelGGL((conv_fixup_kernel<1, 4, 2, 4>), dim3((unsigned)(tiles * 8)), dim3(NT), 0, st, p, grid);
+        if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 4, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
+        else hipLaunchKernelGGL((conv_fixup_kernel<1, 4, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
         e = hipGetLastError();
     }
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
