@@ -153,3 +153,45 @@ def test_resident_forward_equals_the_bf16_operand_forward(C, L, B):
     eng.forward(x, update_stats=True)
     for k, v in eng.arena.buffers.items():
         assert relerr(v.float(), rm1[k].float()) < tol, k
+
+
+def _random_h_geoms(n, seed):
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        tr = bool(rs.randint(2))
+        k, s, p = [(32, 2, 16), (8, 1, 2), (8, 2, 1), (4, 2, 1), (5, 2, 1)][rs.randint(5)]
+        if (k == 5 and not tr) or (k == 4 and tr):
+            continue
+        taps = (k + s - 1) // s if tr else k
+        taps = 1 << (taps - 1).bit_length()
+        nq = 32 // min(taps, 32)
+        Cin = nq * int(rs.randint(1, 24))
+        Cout = int(rs.choice([8, 24, 64, 130, 200]))
+        Lin, B = int(rs.choice([3, 9, 14, 30, 61, 64, 126, 129])), int(rs.randint(1, 7))
+        if not tr and (Lin + 2 * p - k) // s + 1 < 1:
+            continue
+        out.append((tr, Cin, Cout, k, s, p, Lin, B))
+    return out
+
+
+@pytest.mark.parametrize("geom", _random_h_geoms(32, 4102026), ids=lambda g: f"{'T' if g[0] else 'C'}{g[1]}-{g[2]}-k{g[3]}s{g[4]}-L{g[6]}-B{g[7]}")
+def test_conv_fwd_h_random_geometries(geom):
+    """32 seeded random problems of the five (k, stride) families: where pg_conv_fwd_h_supported says yes the result matches the
+    float64 convolution of the bf16 operands; where it says no the call refuses (never a wrong result)."""
+    from phasegen import ops
+    tr, Cin, Cout, k, s, p, Lin, B = geom
+    x = rnd(31, B, Cin, Lin)
+    w = rnd(32, *((Cin, Cout, k) if tr else (Cout, Cin, k))) * 0.1
+    want = (F.conv_transpose1d if tr else F.conv1d)(x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), stride=s, padding=p)
+    xh = ops.h_alloc(B, Cin, Lin, "cuda")
+    ops.cast_rows_bf16(x.cuda(), xh)
+    wh = ops.shadow_weights(w.cuda(), tr, s)
+    y = torch.full(tuple(want.shape), float("nan"), device="cuda")
+    if ops.conv_fwd_h_supported(B, tuple(w.shape), Lin, s, p, tr):
+        ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y)
+        assert relerr(y, want) < 2e-5
+    else:
+        with pytest.raises(RuntimeError, match="not covered"):
+            ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y)

@@ -306,3 +306,43 @@ def test_fused_adam_argument_errors():
         ops.conv_wgrad(x, dy, dw, 2, 1, adam=ops.adam_args(dw, m, v, 1))
     with pytest.raises(ValueError, match="shape"):
         ops.conv_wgrad(x, dy, dw, 2, 1, adam=ops.adam_args(w[:8].contiguous(), m[:8].contiguous(), v[:8].contiguous(), 1))
+
+
+def _random_geoms(n, seed):
+    """Seeded sweep over geometries the fixed list does not hold: every (k, stride) kernel family plus the runtime-(k, s)
+    fallback, paddings up to k - 1, frame counts from one tile column to several samples per tile, channel counts that leave
+    partial slabs and partial tiles."""
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        tr = bool(rs.randint(2))
+        k, s = [(32, 2), (8, 1), (8, 2), (4, 2), (5, 2), (3, 1), (7, 3), (6, 2), (1, 1), (16, 4)][rs.randint(10)]
+        p = int(rs.randint(0, k))
+        Cin, Cout = int(rs.choice([3, 8, 17, 40, 64, 130])), int(rs.choice([5, 16, 33, 72, 136]))
+        Lin, B = int(rs.choice([1, 2, 7, 16, 31, 64, 129])), int(rs.randint(1, 5))
+        Lout = (Lin - 1) * s - 2 * p + k if tr else (Lin + 2 * p - k) // s + 1
+        if Lout < 1 or (not tr and Lin + 2 * p < k):
+            continue
+        out.append((tr, Cin, Cout, k, s, p, Lin, B))
+    return out
+
+
+@pytest.mark.parametrize("geom", _random_geoms(48, 20261004), ids=lambda g: f"{'T' if g[0] else 'C'}{g[1]}-{g[2]}-k{g[3]}s{g[4]}p{g[5]}-L{g[6]}-B{g[7]}")
+def test_conv_random_geometries_vs_torch(geom):
+    """forward / dgrad / wgrad of 48 seeded random geometries (automatic schedule) against fp32 torch on the CPU."""
+    from phasegen import ops
+    tr, Cin, Cout, k, s, p, Lin, B = geom
+    x = rnd(11, B, Cin, Lin)
+    w = rnd(12, *((Cin, Cout, k) if tr else (Cout, Cin, k))) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv_transpose1d(xr, wr, stride=s, padding=p) if tr else F.conv1d(xr, wr, stride=s, padding=p)
+    dy = rnd(13, *yr.shape)
+    yr.backward(dy)
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    y = torch.full(yr.shape, float("nan"), device="cuda")
+    ops.conv_fwd(xd, wd, y, s, p, transposed=tr)
+    dx = torch.full(x.shape, float("nan"), device="cuda")
+    ops.conv_dgrad(dyd, wd, dx, s, p, transposed=tr)
+    dw = torch.full(w.shape, float("nan"), device="cuda")
+    ops.conv_wgrad(xd, dyd, dw, s, p, transposed=tr)
+    assert relerr(y, yr) < TOL and relerr(dx, xr.grad) < TOL and relerr(dw, wr.grad) < TOL
