@@ -299,3 +299,38 @@ def test_preproc_chunker_matches_reference_algorithm(tmp_path):
     from phasegen.data import get_fft_npy_loader                       # and the loader consumes what preproc wrote
     ld = get_fft_npy_loader([str(tmp_path / "Pop_audio_train.npy")], batch_size=4, precon=True)
     assert next(iter(ld))[0].shape == (4, 2, 32, 32)
+
+
+def _random_stft_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        n_fft = int(2 ** rs.randint(5, 13))                      # 32 .. 4096
+        hop = int(rs.choice([n_fft // 4, n_fft // 2, n_fft // 8, max(1, n_fft // 4 - 3), 50]))
+        frames = int(rs.randint(2, 40))
+        n_samp = hop * (frames - 1) + int(rs.randint(0, hop))
+        if n_samp <= n_fft // 2 or n_samp > 200000:
+            continue
+        out.append((n_samp, n_fft, hop, int(rs.randint(1, 4))))
+    return out
+
+
+@pytest.mark.parametrize("n,n_fft,hop,nsig", _random_stft_cases(20, 7))
+def test_stft_istft_random_sizes_vs_oracle(n, n_fft, hop, nsig):
+    """20 seeded random (samples, n_fft, hop) combinations -- every power-of-two transform length, hops that are not n_fft / 4,
+    sample counts that are not multiples of the hop, 2 .. 40 frames: STFT against the oracle in both transform schedules, and
+    ISTFT of that spectrum against the oracle's ISTFT (librosa's conventions; values "parity unpinned", see the file header)."""
+    from phasegen import ops
+    y = np.stack([detgen.make_clip(n, seed=300 + i) for i in range(nsig)])
+    want = np.stack([signal_ref.chunk_and_stft(y[i], n_fft, hop) for i in range(nsig)])
+    yd = torch.from_numpy(y).cuda()
+    for single in (0, 1):
+        S = ops.stft(yd, n_fft, hop, single_frame=single)
+        assert tuple(S.shape) == want.shape and relmax(S, want) < 2e-5
+    frames = want.shape[3]
+    if frames >= 2 and hop * 4 <= n_fft * 2:                     # the overlap-add needs a positive window sum everywhere it keeps
+        back = ops.istft(S[:, 0].contiguous(), S[:, 1].contiguous(), hop, mode=1, normalize=False).cpu().numpy()
+        for i in range(nsig):
+            Z = np.concatenate([np.zeros((1, frames), np.complex64), (want[i, 0] + 1j * want[i, 1]).astype(np.complex64)], 0)
+            w = signal_ref.istft(Z, hop)
+            assert back[i].shape == w.shape and relmax(back[i], w) < 5e-5
