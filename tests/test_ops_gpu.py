@@ -346,3 +346,52 @@ def test_conv_random_geometries_vs_torch(geom):
     dw = torch.full(w.shape, float("nan"), device="cuda")
     ops.conv_wgrad(xd, dyd, dw, s, p, transposed=tr)
     assert relerr(y, yr) < TOL and relerr(dx, xr.grad) < TOL and relerr(dw, wr.grad) < TOL
+
+
+def _bn_cases():
+    # (B, C, L, channel offset of the views inside wider buffers, extra channels of those buffers)
+    return [(64, 24, 256, 0, 0), (64, 16, 256, 8, 16), (64, 16, 126, 0, 0), (64, 16, 126, 3, 5), (64, 12, 129, 0, 0), (64, 12, 61, 1, 2),
+            (7, 20, 128, 0, 4), (5, 9, 4, 0, 0), (3, 7, 2, 2, 2), (1, 6, 1000, 0, 0), (16, 8, 1024, 0, 0), (2, 5, 8192, 0, 0), (3, 4, 6000, 0, 0),
+            (1, 3, 2, 0, 0), (33, 10, 30, 5, 0)]
+
+
+@pytest.mark.parametrize("case", _bn_cases(), ids=lambda c: "B%d-C%d-L%d-off%d+%d" % c)
+def test_bn_flat_walk_variants(case):
+    """The register-resident BatchNorm kernels pick 16-byte, 8-byte or 4-byte units from the frame count and the alignment of
+    every tensor, and walk the channel flat: frame counts divisible by 4 / by 2 / odd, channel VIEWS of wider buffers (the
+    concat buffers of the U-Net: batch stride != C * L, starts that are or are not 16-byte aligned), second activated output,
+    B * L from 1 to 16 384 values per channel, and past that the three-pass fallback -- against F.batch_norm and its autograd."""
+    from phasegen import ops
+    B, C, L, off, extra = case
+    x = rnd(8, B, C, L) * 2 + 0.3
+    g = torch.from_numpy(detgen.uniform(9, (C,), 0.5, 1.5))
+    b = torch.from_numpy(detgen.uniform(10, (C,), -0.5, 0.5))
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.batch_norm(xr, None, None, gr, br, training=True, momentum=0.1, eps=1e-5)
+    dy = rnd(11, B, C, L)
+    yr.backward(dy)
+    Cw = C + off + extra
+
+    def view_of(t=None, fill=float("nan")):
+        buf = torch.full((B, Cw, L), fill, device="cuda")
+        v = buf[:, off:off + C]
+        if t is not None:
+            v.copy_(t.cuda())
+        return buf, v
+
+    _, xv = view_of(x)
+    ybuf, yv = view_of()
+    y2buf, y2v = view_of()
+    sm, si = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_fwd(xv, yv, g.cuda(), b.cuda(), sm, si, y_act=ops.ACT_LEAKY, y2=y2v, y2_act=ops.ACT_RELU)
+    assert relerr(yv, F.leaky_relu(yr, 0.2)) < TOL and relerr(y2v, F.relu(yr)) < TOL
+    if off or extra:                                                   # nothing outside the view was written
+        rest = torch.cat([ybuf[:, :off], ybuf[:, off + C:]], 1)
+        assert bool(torch.isnan(rest).all())
+    _, dyv = view_of(dy)
+    dxbuf, dxv = view_of()
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_bwd(xv, dyv, dxv, g.cuda(), sm, si, dg, db)
+    assert relerr(dxv, xr.grad) < TOL and relerr(dg, gr.grad) < TOL and relerr(db, br.grad) < TOL
+    if off or extra:
+        assert bool(torch.isnan(torch.cat([dxbuf[:, :off], dxbuf[:, off + C:]], 1)).all())
