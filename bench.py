@@ -25,9 +25,16 @@ Rank 0 prints ONE JSON line (contract in the task statement).  How the numbers a
                         of the parameter arena compared across ranks (a diverged replica FAILS the bench), each bucket's
                         all-reduce timed alone, the compute-only step and the fraction of communication hidden under backward.
 
-Other configurations (never the default, never what the driver records):
-    --config fwd   BASELINE configs[1]: forward only, batch 32 x 1024 x 256, fp32
-    --config e2e   BASELINE configs[4]: stereo clips -> STFT 2048/512 + polar -> U-Net forward (bf16 MFMA operands) -> ISTFT
+  other_configs         (N = 1, fp32 headline run only) the other BASELINE configurations measured in the SAME process, so that the
+                        driver's record carries them too -- never as `value`:
+                          fwd            configs[1]: forward only, batch 32 x 1024 x 256, fp32 (+ encoder_convs = D0-D3 together)
+                          e2e            configs[4]: 32 stereo clips -> STFT 2048/512 + polar -> U-Net forward on the bf16-resident
+                                         kernels -> ISTFT, with its own roofline against the dense bf16 MFMA peak
+                          ref_default    the reference's own defaults (train.py:14-15): full step at batch 16 x 1024 x 128
+                          dp_equivalent  the headline step with the Adam update NOT fused into the wgrad epilogues (per-layer
+                                         slices on a side stream): what every rank of an N > 1 run executes, i.e. the N = 1 figure
+                                         a scaling efficiency should divide by
+                        Each can also be the whole line: --config fwd | e2e (same code, same numbers).
 """
 import argparse
 import json
@@ -224,6 +231,12 @@ def dp_diagnostics(torch, dist, trainer, batch, world, step_ms):
     red.enabled = True
     nocomm = float(t.item())
     exposed = max(0.0, step_ms - nocomm)
+    B, L = batch.shape[0], batch.shape[3]
+    out["dp_equivalent"] = {"ms_per_step": round(nocomm, 3), "frames_per_s_per_gpu": B * L / nocomm * 1e3,
+                            "efficiency": round(nocomm / step_ms, 4),
+                            "note": "this run's own step with the all-reduce switched off (side-stream Adam, contended work split): "
+                                    "efficiency = value / (n_gpus x frames_per_s_per_gpu); the N = 1 line carries the same step as "
+                                    "other_configs.dp_equivalent"}
     out.update({"allreduce_alone_ms": {k: round(v, 3) for k, v in alone.items()}, "allreduce_alone_total_ms": round(total, 3),
                 "allreduce_payload_bytes": payload,
                 "allreduce_busbw_GBps": round(payload * 2 * (world - 1) / max(world, 1) / (total * 1e-3) / 1e9, 1),
@@ -326,6 +339,8 @@ def run_train(a, torch, dist, world, rank, local):
             other[mode] = {"ms_per_step": d1 * 1e3, "frames_per_s": B * L / d1, "step_tflops": round(step_flops / d1 / 1e12, 2)}
         model.engine.precision = ops.precision_code("fp32")
         out["other_precisions"] = other
+    if world == 1 and a.precision == "fp32" and not a.no_other_configs and (C, L, B) == (1024, 256, 64):
+        out["other_configs"] = other_configs(torch, dist, model, C, L, B)
     if world == 1 and not a.no_cpu_baseline and a.precision == "fp32":
         del trainer, model, batch
         torch.cuda.empty_cache()
@@ -336,24 +351,16 @@ def run_train(a, torch, dist, world, rank, local):
         raise SystemExit(3)
 
 
-def run_fwd(a, torch, dist, world, rank, local):
-    """BASELINE configs[1]: forward only (train-mode BatchNorm, as the reference always runs it), batch 32 x 1024 x 256."""
-    from phasegen import ops
-    from phasegen.model import UNetModel
-    C, L, B = a.channels, a.frames, (a.batch if a.batch != 64 else 32)
-    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-    torch.manual_seed(0)
-    model = UNetModel(C, 2 * C, gpu_ids=[local], precision=a.precision)
-    x = synthetic_batch(torch, B, C, L, 1 + rank)[:, 0].contiguous()
-    fwd = lambda: model.engine.forward(x, update_stats=True)
-    for _ in range(a.warmup):
-        fwd()
+def _timed(torch, dist, world, fn, warmup, steps):
+    """`warmup` untimed calls, then `steps` calls bracketed by barrier + synchronize; max over ranks.  Seconds per call."""
+    for _ in range(warmup):
+        fn()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        fwd()
+    for _ in range(steps):
+        fn()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -362,41 +369,46 @@ def run_fwd(a, torch, dist, world, rank, local):
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt / steps
+
+
+def measure_fwd(torch, dist, world, rank, model, C, L, B, warmup, steps, precision="fp32"):
+    """BASELINE configs[1]: forward only (train-mode BatchNorm, as the reference always runs it), batch 32 x 1024 x 256."""
+    from phasegen import ops
+    peak = PEAK_FP32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    x = synthetic_batch(torch, B, C, L, 1 + rank)[:, 0].contiguous()
+    fwd = lambda: model.engine.forward(x, update_stats=True)
+    sec = _timed(torch, dist, world, fwd, warmup, steps)
     fl = conv_flops(C, L, B)
-    step_ms = dt / a.steps * 1e3
+    step_ms = sec * 1e3
     ks, by = kernel_pass(torch, ops, fwd, 3, fl, peak, step_ms)
-    if rank != 0:
-        return
     enc = sum(fl[n] for n in ("D0", "D1", "D2", "D3")) / sum(ks[n + ".fwd"]["ms"] for n in ("D0", "D1", "D2", "D3")) / 1e9
-    print(json.dumps({
-        "metric": "spectrogram-frames/sec (forward only)", "value": world * B * L * a.steps / dt, "unit": "frames/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True,
-        "scaling": "weak (replicas only)", "vs_baseline": None, "dtype": DTYPES[a.precision], "data": "synthetic",
+    return {
+        "metric": "spectrogram-frames/sec (forward only)", "value": world * B * L / sec, "unit": "frames/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": step_ms, "higher_is_better": True,
+        "scaling": "weak (replicas only)", "vs_baseline": None, "dtype": DTYPES[precision], "data": "synthetic",
         "config": {"workload": f"UNetModel({C}, {2 * C}).forward, train-mode BatchNorm, batch {B} x {C} bins x {L} frames (BASELINE configs[1])",
                    "global_batch": world * B, "frames": L, "channels": C},
-        "roofline": roofline_of(by, peak, sum(fl.values()) / (dt / a.steps) / 1e12, a.precision, False),
+        "roofline": roofline_of(by, peak, sum(fl.values()) / sec / 1e12, precision, False),
         "encoder_convs": {"tflops": round(enc, 2), "frac": round(enc / peak, 4),
                           "note": "D0-D3 forward together: BASELINE.json's '>= 50 % of the MFMA-fp32 roofline on the encoder convs'"},
-        "kernels": ks}), flush=True)
+        "kernels": ks}
 
 
-def run_e2e(a, torch, dist, world, rank, local):
+def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf16"):
     """BASELINE configs[4]: stereo clips (2 mono signals each) of 130 560 samples -> STFT 2048/512 fused with log1p|z| / angle ->
-    U-Net forward (bf16 MFMA operands by default) -> ISTFT of (exp(m) - 1) e^{j phi}.  No exchange step: ranks are replicas."""
+    U-Net forward (bf16-resident operands by default) -> ISTFT of (exp(m) - 1) e^{j phi}.  No exchange step: ranks are replicas."""
     from phasegen import audio, ops
-    from phasegen.model import UNetModel
     n_fft, hop, n = 2048, 512, 255 * 512
-    prec = a.precision if a.precision_given else "bf16"
     peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
-    C, clips = n_fft // 2, (a.batch if a.batch != 64 else 32)
+    C = n_fft // 2
     nsig, frames = 2 * clips, 1 + n // hop
-    torch.manual_seed(0)
-    model = UNetModel(C, 2 * C, gpu_ids=[local], precision=prec)
     g = torch.Generator(device="cuda").manual_seed(1 + rank)
     wav = torch.randn(nsig, n, device="cuda", generator=g) * 0.1
     polar = torch.empty(nsig, 2, C, frames, device="cuda")
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     stage = [0.0, 0.0, 0.0]
+    res = {}
 
     def step(record=False):
         if record:
@@ -407,48 +419,89 @@ def run_e2e(a, torch, dist, world, rank, local):
         pred = model.engine.forward(polar[:, 0], update_stats=False, inference=True)
         if record:
             ev[2].record()
-        outs = [audio.synthesize(polar[i:i + 64, 0], pred[i:i + 64, :C], hop) for i in range(0, nsig, 64)]
+        res["out"] = [audio.synthesize(polar[i:i + 64, 0], pred[i:i + 64, :C], hop) for i in range(0, nsig, 64)]
         if record:
             ev[3].record()
             torch.cuda.synchronize()
             for i in range(3):
                 stage[i] += ev[i].elapsed_time(ev[i + 1])
-        return outs
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    sec = _timed(torch, dist, world, step, warmup, steps)
+    out = res["out"]
     assert out[0].shape == (min(64, nsig), hop * (frames - 1)) and bool(torch.isfinite(out[0]).all())
     for _ in range(3):
         step(True)
     fl = conv_flops(C, frames, nsig)
-    step_ms = dt / a.steps * 1e3
-    ks, by = kernel_pass(torch, ops, lambda: model.engine.forward(polar[:, 0], update_stats=False, inference=True), 3, fl, peak, step_ms)
-    if rank != 0:
-        return
-    print(json.dumps({
-        "metric": "spectrogram-frames/sec end to end (STFT + U-Net forward + ISTFT)", "value": world * nsig * frames * a.steps / dt,
-        "unit": "frames/s", "clips_per_s": world * clips * a.steps / dt, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+    step_ms = sec * 1e3
+    fwd_ms = stage[1] / 3
+    ks, by = kernel_pass(torch, ops, lambda: model.engine.forward(polar[:, 0], update_stats=False, inference=True), 3, fl, peak, fwd_ms)
+    roof = roofline_of(by, peak, sum(fl.values()) / (fwd_ms * 1e-3) / 1e12, prec, False)
+    roof["step_frac_of"] = "U-Net forward stage (8 convs + 6 BatchNorms + input cast): all conv FLOPs / stage time / peak"
+    dom = roof["kernel"].split(" (")[0]
+    roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
+    return {
+        "metric": "spectrogram-frames/sec end to end (STFT + U-Net forward + ISTFT)", "value": world * nsig * frames / sec,
+        "unit": "frames/s", "clips_per_s": world * clips / sec, "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak (replicas only)", "vs_baseline": None,
         "dtype": DTYPES[prec], "data": "synthetic",
         "config": {"workload": f"BASELINE configs[4]: {clips} stereo clips x {n} samples per rank, 2048-FFT / 512-hop, "
                                f"STFT+polar -> UNetModel({C}, {2 * C}).forward -> ISTFT", "signals_per_rank": nsig, "frames": frames},
-        "stage_ms": {"stft+polar": stage[0] / 3, "unet_forward": stage[1] / 3, "istft": stage[2] / 3},
-        "roofline": roofline_of(by, peak, sum(fl.values()) / (stage[1] / 3 * 1e-3) / 1e12, prec, False),
-        "kernels": ks}), flush=True)
+        "stage_ms": {"stft+polar": stage[0] / 3, "unet_forward": fwd_ms, "istft": stage[2] / 3},
+        "roofline": roof, "kernels": ks}
+
+
+def measure_train(torch, model, B, C, L, seed, fuse_adam, warmup, steps):
+    """A full train.py:41-62 step at another shape / update placement on the SAME model (N = 1): ms and frames/s only."""
+    from phasegen.trainer import Trainer
+    trainer = Trainer(model, lr=1e-3, fuse_adam=fuse_adam)
+    batch = synthetic_batch(torch, B, C, L, seed)
+    sec = _timed(torch, None, 1, lambda: trainer.step(batch), warmup, steps)
+    fl = conv_flops(C, L, B)
+    tf = (3 * sum(fl.values()) - fl["D0"]) / sec / 1e12
+    return {"ms_per_step": sec * 1e3, "frames_per_s": B * L / sec, "steps": steps, "warmup": warmup, "batch": B, "frames": L,
+            "channels": C, "step_tflops": round(tf, 2), "step_frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+            "adam": "fused into the wgrad epilogues" if trainer.fuse_adam else "per-layer slices on a side stream"}
+
+
+def other_configs(torch, dist, model, C, L, B):
+    """The other BASELINE configurations on the headline run's model (N = 1, fp32), each a few seconds."""
+    from phasegen import ops
+    out = {}
+    out["dp_equivalent"] = dict(measure_train(torch, model, B, C, L, 1, False, 2, 5),
+                                note="the headline step with fuse_adam=False: what every rank of an N > 1 run executes")
+    out["ref_default"] = dict(measure_train(torch, model, 16, C, 128, 3, True, 2, 10),
+                              note="the reference's own defaults, train.py:14-15: batch 16, 1024 bins x 128 frames")
+    f = measure_fwd(torch, dist, 1, 0, model, C, L, 32, 3, 10)
+    out["fwd"] = {k: f[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "encoder_convs")}
+    out["fwd"]["roofline"] = {k: v for k, v in f["roofline"].items() if k != "by_kernel"}
+    old = model.engine.precision
+    model.engine.precision = ops.precision_code("bf16")
+    try:
+        e = measure_e2e(torch, dist, 1, 0, model, 32, 3, 10)
+    finally:
+        model.engine.precision = old
+    out["e2e"] = {k: e[k] for k in ("metric", "value", "unit", "clips_per_s", "ms_per_step", "dtype", "config", "stage_ms", "roofline")}
+    return out
+
+
+def run_fwd(a, torch, dist, world, rank, local):
+    from phasegen.model import UNetModel
+    C, L, B = a.channels, a.frames, (a.batch if a.batch != 64 else 32)
+    torch.manual_seed(0)
+    model = UNetModel(C, 2 * C, gpu_ids=[local], precision=a.precision)
+    out = measure_fwd(torch, dist, world, rank, model, C, L, B, a.warmup, a.steps, a.precision)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def run_e2e(a, torch, dist, world, rank, local):
+    from phasegen.model import UNetModel
+    prec = a.precision if a.precision_given else "bf16"
+    torch.manual_seed(0)
+    model = UNetModel(1024, 2048, gpu_ids=[local], precision=prec)
+    out = measure_e2e(torch, dist, world, rank, model, (a.batch if a.batch != 64 else 32), a.warmup, a.steps, prec)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def main():
@@ -479,6 +532,7 @@ def main():
     ap.add_argument("--serial-adam", action="store_true", help="A/B: one Adam launch after backward instead of per-layer slices on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-precisions", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the fwd / e2e / ref_default / dp_equivalent legs of the default line")
     ap.add_argument("--cpu-threads", type=int, default=None)
     a = ap.parse_args()
     a.precision_given = a.precision is not None

@@ -278,3 +278,47 @@ def test_loader_refuses_less_than_one_global_batch():
     data = torch.zeros(31, 1)
     with pytest.raises(ValueError, match="global batch"):
         list(SpectrogramLoader(data, torch.zeros(31, 1), 16, True, 0, 2, seed=0))
+
+
+def replica_worker(rank, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from phasegen.trainer import sync_replicas
+        from phasegen.unet import ParamArena
+        arena = ParamArena(C, torch.device("cpu"))
+        arena.load_numpy(detgen.make_params(C, seed=0))
+        sync_replicas(arena, None, "check")                                  # identical replicas pass
+        arena.p(detgen.param_order()[3]).view(-1)[5] += 1e-3 * rank          # rank 1 now differs in ONE element
+        try:
+            sync_replicas(arena, None, "check")
+            raised = False
+        except RuntimeError as e:
+            raised = "replicas differ" in str(e)
+        arena.buffers[detgen.BN_KEYS[0] + ".running_var"][2] += 0.5 * rank   # ... and in one BatchNorm buffer
+        sync_replicas(arena, None, "broadcast")
+        sync_replicas(arena, None, "check")                                  # rank 0's state everywhere
+        q.put((rank, raised, arena.flat.clone().numpy(), arena.buffers[detgen.BN_KEYS[0] + ".running_var"].clone().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_refuses_diverged_replicas_and_can_broadcast():
+    """default-initialised weights come from torch's global RNG, so ranks that were not seeded identically would
+    train diverged replicas silently.  Trainer.__init__ compares a checksum across ranks (raises) or broadcasts rank 0's state."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ps = [ctx.Process(target=replica_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in ps:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(WORLD)), key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(g[1] for g in got)                       # every rank saw the mismatch
+    assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])

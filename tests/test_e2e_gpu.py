@@ -84,13 +84,51 @@ def test_e2e_chain_full_size_properties():
     torch.manual_seed(5)
     m32 = UNetModel(C, 2 * C, precision="fp32")
     m16 = UNetModel(C, 2 * C, precision="bf16")
-    m16.engine.arena.flat.copy_(m32.engine.arena.flat)
-    m16.engine.arena.touch()                                   # parameters rewritten behind the engine's back: refresh bf16 shadows
+    m16.engine.arena.flat.copy_(m32.engine.arena.flat)         # an in-place torch write: the bf16 shadows notice it by themselves
     p32 = m32.engine.forward(polar[:, 0], update_stats=False).clone()
     _, p16, out = device_chain(m16, wav, n_fft, hop)
     assert relmax(p16, p32) < 3e-2
     assert tuple(out.shape) == (nsig, hop * (L - 1)) and bool(torch.isfinite(out).all())
     assert float((out.abs().amax(dim=1) - 1).abs().max()) < 1e-6
+
+
+def test_bf16_shadows_follow_in_place_parameter_writes_by_torch():
+    """the bf16 weight shadows of the resident inference forward were keyed on the hand-bumped arena.version only, so
+    an in-place write torch makes through a parameter view -- torch.optim.Adam(model.parameters()).step(), the reference's own
+    optimiser (train.py:26), or p.data.copy_ -- left them stale.  They are now also keyed on arena.flat._version."""
+    from phasegen.model import UNetModel
+    C, L, B = 32, 64, 3
+    torch.manual_seed(11)
+    model = UNetModel(C, 2 * C, precision="bf16")
+    x = torch.from_numpy(detgen.make_batch(B, C, L, seed=4)).cuda()
+    with torch.no_grad():
+        y0 = model.forward(x[:, 0]).clone()                    # builds the shadows
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)        # stock torch optimiser on the arena's parameter views
+    pred = model.forward(x[:, 0])
+    (pred * pred).mean().backward()
+    opt.step()
+    with torch.no_grad():
+        y1 = model.forward(x[:, 0]).clone()                    # must multiply by the UPDATED weights
+    fresh = UNetModel(C, 2 * C, precision="bf16")
+    fresh.engine.arena.flat.copy_(model.engine.arena.flat)
+    for k, v in model.engine.arena.buffers.items():
+        fresh.engine.arena.buffers[k].copy_(v)
+    with torch.no_grad():
+        want = fresh.forward(x[:, 0])
+    assert torch.equal(y1, want)
+    assert relmax(y1, y0) > 1e-3                               # the step did move the output: a stale shadow would have given y0
+    p0 = next(iter(model.parameters()))
+    with torch.no_grad():
+        p0.mul_(0.5)                                           # a plain in-place write under no_grad
+        y2 = model.forward(x[:, 0]).clone()
+        p0.detach().mul_(2.0)                                  # ... and one through a detached alias: back to y1's weights
+        y3 = model.forward(x[:, 0]).clone()
+    assert relmax(y2, y1) > 1e-3 and torch.equal(y3, y1)
+    # (`p.data` hands out a tensor with its OWN version counter: a write through it is invisible to torch and needs arena.touch())
+    with torch.no_grad():
+        p0.data.mul_(0.5)
+        model.engine.arena.touch()
+        assert torch.equal(model.forward(x[:, 0]), y2)
 
 
 def test_resident_forward_falls_back_where_windows_do_not_fit():
@@ -159,7 +197,7 @@ def test_two_threads_two_streams_two_precisions():
     assert relmax(results["fp32"], want["fp32"]) < 2e-5
     assert relmax(results["bf16"], want["bf16"]) < 2e-5
     assert ops._tls.precision == 0                                  # the main thread's default was never touched
-    assert len({k for k in ops._conv_ws if k[0].type == "cuda"}) >= 2   # one stream-K workspace per stream
+    assert len({k for k in ops._conv_ws.d if k[0].type == "cuda"}) >= 2   # one stream-K workspace per stream
 
 
 def test_tensor_on_another_device_is_refused_not_faulted():

@@ -36,7 +36,7 @@ def test_conv_layer_at_full_size(layer, schedule):
 
 @pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
 def test_conv_layer_at_full_size_bf16_operands(layer):
-    """The same checks with pg_conv_set_precision(1).  x, w and dy are made bf16-representable, so the operand rounding
+    """The same checks with pg_conv_args.precision = PG_PREC_BF16.  x, w and dy are made bf16-representable, so the operand rounding
     only acts on LeakyReLU outputs (0.2 x is not representable) and the host recomputation -- on the rounded activated
     operand -- is exact for the raw-window kernels and for the fp32 fallback passes alike."""
     from phasegen import ops
@@ -49,7 +49,7 @@ def test_conv_layer_at_full_size_bf16_operands(layer):
 
 @pytest.mark.parametrize("layer", [LAYERS[0], LAYERS[2], LAYERS[4], LAYERS[7]], ids=["D0", "D2", "U3", "U0"])
 def test_conv_layer_at_full_size_bf16x3_split(layer):
-    """pg_conv_set_precision(2) at the real geometry: the same float64 spot values (UNROUNDED operands, 1e-4 of max-abs)
+    """pg_conv_args.precision = PG_PREC_BF16X3 at the real geometry: the same float64 spot values (UNROUNDED operands, 1e-4 of max-abs)
     and adjoint identities as the fp32 path."""
     from phasegen import ops
     ops.set_conv_precision("bf16x3")

@@ -97,7 +97,7 @@ def bf16_round(t):
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("mode", [1, 6], ids=["raw/tile-per-wg", "im2col/stream-k"])
 def test_conv_bf16_operand_mode(geom, act, mode):
-    """pg_conv_set_precision(1) (BASELINE config 5): operands rounded to bf16 (RNE) AFTER the fused activation, fp32
+    """pg_conv_args.precision = PG_PREC_BF16 (BASELINE config 5): operands rounded to bf16 (RNE) AFTER the fused activation, fp32
     accumulate, in every conv kernel.  Oracle = float64 autograd of the same conv on the rounded tensors, so only the
     accumulation order differs: 2e-5 (against the unrounded fp32 oracle the same outputs are ~3e-3 off)."""
     from phasegen import ops
@@ -127,7 +127,7 @@ def test_conv_bf16_operand_mode(geom, act, mode):
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("mode", [1, 6], ids=["raw/tile-per-wg", "im2col/stream-k"])
 def test_conv_bf16x3_split_mode_meets_the_fp32_bound(geom, mode):
-    """pg_conv_set_precision(2): fp32 operands split hi + lo into bf16 pairs, three bf16 MFMA products, fp32 accumulate.
+    """pg_conv_args.precision = PG_PREC_BF16X3: fp32 operands split hi + lo into bf16 pairs, three bf16 MFMA products, fp32 accumulate.
     Checked against the UNROUNDED float64 convolution: the dropped lo*lo term and the split residuals are <= 2^-18 of a
     product, so the result sits ~5e-6 from exact -- 20x inside the 1e-4 parity bound (fp32 MFMA: ~1e-6)."""
     from phasegen import ops
@@ -306,6 +306,20 @@ def test_fused_adam_argument_errors():
         ops.conv_wgrad(x, dy, dw, 2, 1, adam=ops.adam_args(dw, m, v, 1))
     with pytest.raises(ValueError, match="shape"):
         ops.conv_wgrad(x, dy, dw, 2, 1, adam=ops.adam_args(w[:8].contiguous(), m[:8].contiguous(), v[:8].contiguous(), 1))
+    # the library itself (a C caller has no Python wrapper in front of it) refuses p / m / v of another size
+    import ctypes
+    from phasegen import _lib
+    a = ops._conv_args(False, 2, 8, 16, 24, 4, 2, 1, x.device)
+    a.x, a.x_bs = ops._act3(x, "x")
+    a.dy, a.dy_bs = ops._act3(dy, "dy")
+    a.dw = dw.data_ptr()
+    ad = ops.adam_args(w, m, v, 1)
+    ad.n = w.numel() - 4
+    a.adam = ctypes.addressof(ad)
+    before = w.clone()
+    assert _lib.load().pg_conv1d_wgrad(ctypes.byref(a), ops._stream()) == _lib.ERR_SHAPE
+    torch.cuda.synchronize()
+    assert torch.equal(w, before)
 
 
 def _random_geoms(n, seed):

@@ -54,7 +54,7 @@ def test_train_then_demo(tmp_path):
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_train_accepts_the_precision_modes(tmp_path, precision):
-    """--precision selects the MFMA operand mode (pg_conv_set_precision) for the whole run; the losses of the first
+    """--precision selects the MFMA operand mode (pg_conv_args.precision, carried by the engine) for the whole run; the losses of the first
     steps stay close to the fp32 run's (same synthetic clips, same initialisation)."""
     import re
     args = [os.path.join(PKG, "train.py"), "--channels", "16", "--batch_size", "2", "--max_steps", "3", "--synthetic", "4",

@@ -336,6 +336,7 @@ static int set_fused_adam(IgemmParams& p, const pg_conv_args* a) {
     if (!ad) return PG_OK;
     if (!ad->p || !ad->m || !ad->v) return pg_fail(PG_ERR_NULL, "wgrad: fused adam needs p, m and v");
     if (ad->step < 1) return pg_fail(PG_ERR_SHAPE, "wgrad: fused adam: step is 1-based");
+    if (ad->n != (int64_t)a->Cin * a->Cout * a->k) return pg_fail(PG_ERR_SHAPE, "wgrad: fused adam: n must equal Cin * Cout * k (p / m / v shaped like dw)");
     if (((uintptr_t)ad->p | (uintptr_t)ad->m | (uintptr_t)ad->v) & 3) return pg_fail(PG_ERR_ALIGN, "wgrad: fused adam: misaligned pointer");
     if ((const float*)ad->p == a->dw || ad->m == a->dw || ad->v == a->dw) return pg_fail(PG_ERR_SHAPE, "wgrad: fused adam: p / m / v alias dw");
     p.ad_p = ad->p; p.ad_m = ad->m; p.ad_v = ad->v;

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libphasegen.so")
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2           # pg_conv_args.precision
+OK, ERR_NULL, ERR_SHAPE, ERR_ALIGN, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4, -5   # return codes (PG_ERR_*)
 OP_CONV1D_FWD, OP_CONV1D_DGRAD, OP_CONV1D_WGRAD, OP_CONVT1D_FWD, OP_CONVT1D_DGRAD, OP_CONVT1D_WGRAD = range(6)   # pg_conv_describe
 SCHED_AUTO, SCHED_TILE_PER_WG, SCHED_FORCE_STREAMK, SCHED_NO_RAW, SCHED_NO_TALL, SCHED_CONTENDED = 0, 1, 2, 4, 8, 16   # pg_conv_args.schedule bits
 

@@ -116,7 +116,33 @@ def convt_out_len(Lin, k, s, p):
     return (Lin - 1) * s - 2 * p + k
 
 
-_conv_ws = {}
+class _StreamCache:
+    """Scratch buffers keyed by (device, stream handle), bounded: at most ``cap`` streams per cache, least recently used evicted.
+    A buffer is allocated while its stream is the CURRENT one, so torch's caching allocator ties the block to that stream: an
+    evicted (or released) buffer goes back to that stream's pool, and whoever reuses the block is ordered after the stream's
+    pending work -- also when a stream handle is recycled after the evicted entry's stream died."""
+
+    def __init__(self, cap=4):
+        self.cap = cap
+        self.d = {}
+
+    def get(self, device, nbytes_fn, at_least=0):
+        device = torch.device(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        buf = self.d.pop(key, None)                     # re-inserted below: dicts keep insertion order -> LRU
+        if buf is None or buf.numel() < at_least:
+            buf = torch.empty(max(nbytes_fn(), at_least), device=device, dtype=torch.uint8)
+        self.d[key] = buf
+        while len(self.d) > self.cap:
+            self.d.pop(next(iter(self.d)))
+        return buf
+
+    def clear(self):
+        self.d.clear()
+
+
+_conv_ws = _StreamCache()
+_caches = [_conv_ws]
 
 
 def _ws_key(device):
@@ -126,13 +152,16 @@ def _ws_key(device):
 
 
 def conv_workspace(device):
-    """Scratch for the conv kernels' stream-K schedule (pg_workspace_bytes_conv(), 128 MiB), one per (device, STREAM):
-    launches on one stream are ordered and may share it, launches on different streams may overlap and must not."""
-    key = _ws_key(device)
-    ws = _conv_ws.get(key)
-    if ws is None:
-        ws = _conv_ws[key] = torch.empty(_lib.load().pg_workspace_bytes_conv(), device=device, dtype=torch.uint8)
-    return ws
+    """Scratch for the conv kernels' stream-K schedule (pg_workspace_bytes_conv(), 512 MiB), one per (device, STREAM):
+    launches on one stream are ordered and may share it, launches on different streams may overlap and must not.  At most four
+    streams per device hold one at a time (least recently used is dropped); ``release_workspaces()`` drops them all."""
+    return _conv_ws.get(device, _lib.load().pg_workspace_bytes_conv)
+
+
+def release_workspaces():
+    """Drop every cached scratch buffer (conv stream-K, loss, ISTFT, overlap-add, moments): they are re-created on demand."""
+    for c in _caches:
+        c.clear()
 
 
 # ---- per-call knobs ---------------------------------------------------------------------------------------------
@@ -443,7 +472,8 @@ def bn_bwd(x, dy, dx, gamma, save_mean, save_invstd, dgamma, dbeta):
     return dx
 
 
-_loss_ws = {}
+_loss_ws = _StreamCache()
+_caches.append(_loss_ws)
 
 
 def loss_fwd_bwd(pred, batch, dpred=None, losses=None, mag_weight=0.2):
@@ -462,11 +492,8 @@ def loss_fwd_bwd(pred, batch, dpred=None, losses=None, mag_weight=0.2):
     a.losses = _dense(losses, "losses")
     lib = _lib.load()
     need = lib.pg_workspace_bytes_loss(C.byref(a))
-    ws = _loss_ws.get(_ws_key(pred.device))
-    if ws is None or ws.numel() * 4 < need:
-        ws = torch.empty((need + 3) // 4, device=pred.device, dtype=torch.float32)
-        _loss_ws[_ws_key(pred.device)] = ws
-    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    ws = _loss_ws.get(pred.device, lambda: need, need)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     _lib.check(lib.pg_loss_fwd_bwd(C.byref(a), _stream()), "loss_fwd_bwd")
     return losses
 
@@ -517,17 +544,15 @@ def stft(y, n_fft, hop, polar=False, out=None, single_frame=None, chunk_start=No
     return out
 
 
-_moments_ws = {}
+_moments_ws = _StreamCache()
+_caches.append(_moments_ws)
 
 
 def standardize_(x):
     """preproc_mdb.py:182 in place on a dense float32 tensor: x = (x - x.mean()) / x.std() over the WHOLE array (population
     std, moments reduced in double).  Returns the (mean, std) device tensor (2 doubles)."""
     lib = _lib.load()
-    key = _ws_key(x.device)
-    ws = _moments_ws.get(key)
-    if ws is None:
-        ws = _moments_ws[key] = torch.empty(lib.pg_workspace_bytes_moments(), dtype=torch.uint8, device=x.device)
+    ws = _moments_ws.get(x.device, lib.pg_workspace_bytes_moments)
     stats = torch.empty(2, dtype=torch.float64, device=x.device)
     a = _lib.MomentsArgs()
     a.n, a.x, a.stats = x.numel(), _dense(x, "x"), stats.data_ptr()
@@ -556,7 +581,8 @@ def polar(d, out=None, use_exp=True):
     return out
 
 
-_istft_ws = {}
+_istft_ws = _StreamCache()
+_caches.append(_istft_ws)
 
 
 def istft(a_t, b_t, hop, mode=0, normalize=True, single_frame=None):
@@ -574,10 +600,7 @@ def istft(a_t, b_t, hop, mode=0, normalize=True, single_frame=None):
         a.b, a.b_bs = _act3(b_t[s0:s1], "b")
         a.audio = audio[s0:s1].data_ptr()
         need = lib.pg_workspace_bytes_istft(C.byref(a))
-        ws = _istft_ws.get(_ws_key(a_t.device))
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(need, device=a_t.device, dtype=torch.uint8)
-            _istft_ws[_ws_key(a_t.device)] = ws
+        ws = _istft_ws.get(a_t.device, lambda: need, need)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(lib.pg_istft(C.byref(a), _stream()), "istft")
     return audio
@@ -593,7 +616,8 @@ def gl_project(S, mag, x, spec_out=None):
     _lib.check(_lib.load().pg_gl_project(C.byref(a), _stream()), "gl_project")
 
 
-_ola_ws = {}
+_ola_ws = _StreamCache()
+_caches.append(_ola_ws)
 
 
 def ola_nt(frames_nt, hop, audio, normalize=False):
@@ -602,9 +626,7 @@ def ola_nt(frames_nt, hop, audio, normalize=False):
     a.n_fft, a.frames = frames_nt.shape
     a.hop, a.normalize = hop, int(normalize)
     a.fr, a.audio = _dense(frames_nt, "frames"), _dense(audio, "audio")
-    ws = _ola_ws.get(_ws_key(audio.device))
-    if ws is None:
-        ws = _ola_ws[_ws_key(audio.device)] = torch.empty(256, device=audio.device, dtype=torch.uint8)
+    ws = _ola_ws.get(audio.device, lambda: 256)
     a.workspace, a.workspace_bytes = ws.data_ptr(), 256
     _lib.check(_lib.load().pg_ola_nt(C.byref(a), _stream()), "ola_nt")
     return audio

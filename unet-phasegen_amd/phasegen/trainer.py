@@ -93,6 +93,43 @@ class BucketedAllReduce:
         return done
 
 
+def arena_checksum(arena):
+    """Two moments (sum, sum of squares; fp64) of the parameter arena followed by those of every floating BatchNorm buffer."""
+    parts = [arena.flat] + [arena.buffers[k] for k in sorted(arena.buffers) if arena.buffers[k].is_floating_point()]
+    chk = torch.zeros(2 * len(parts), device=arena.flat.device, dtype=torch.float64)
+    for i, t in enumerate(parts):
+        t = t.reshape(-1)
+        for s0 in range(0, t.numel(), 1 << 26):          # chunked: no second fp64 copy of a 2.45 GB arena
+            c = t[s0:s0 + (1 << 26)].double()
+            chk[2 * i] += c.sum()
+            chk[2 * i + 1] += (c * c).sum()
+    return chk
+
+
+def sync_replicas(arena, group=None, mode="check"):
+    """See Trainer.__init__.  No-op without an initialised process group or at world size 1."""
+    if mode not in ("check", "broadcast", None):
+        raise ValueError("replicas: 'check', 'broadcast' or None")
+    if mode is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return
+    if mode == "broadcast":
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(arena.flat, src=src, group=group)
+        for k in sorted(arena.buffers):
+            dist.broadcast(arena.buffers[k], src=src, group=group)
+        if hasattr(arena, "touch"):
+            arena.touch()
+        return
+    chk = arena_checksum(arena)
+    got = [torch.empty_like(chk) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(got, chk, group=group)
+    bad = [r for r, t in enumerate(got) if not torch.equal(got[0], t)]
+    if bad:
+        raise RuntimeError(f"phasegen.Trainer: data-parallel replicas differ at construction (group ranks {bad} vs rank 0): seed every "
+                           "rank identically before building the model (torch.manual_seed), load the same checkpoint everywhere, "
+                           "or pass replicas='broadcast'")
+
+
 class Trainer:
     """``loss_fn(pred, batch, dpred, losses, mag_weight)`` and ``optim`` default to the device kernels (pg_loss_fwd_bwd,
     fused Adam).  They are injection points for tests/test_dp_gloo.py, which drives THIS step's control flow (bucket launches
@@ -100,9 +137,16 @@ class Trainer:
     passes them."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None, mag_weight=0.2, always_reduce=False,
-                 grad_compress=None, loss_fn=None, optim=None, overlap_adam=True, fuse_adam=True):
+                 grad_compress=None, loss_fn=None, optim=None, overlap_adam=True, fuse_adam=True, replicas="check"):
         self.model = model
         self.engine = model.engine
+        # Data parallel assumes identical replicas at the start (data_parallel, model.py:40-41, re-broadcasts the parameters every
+        # forward; here they are only ever changed by identical updates).  Default-initialised weights come from torch's global
+        # RNG, so a caller who forgets torch.manual_seed on every rank would train diverged replicas silently:
+        #   replicas="check"      (default) compare a checksum of parameters + BatchNorm buffers across ranks, raise on mismatch
+        #   replicas="broadcast"  copy rank 0's parameters and buffers to every rank
+        #   replicas=None         trust the caller
+        sync_replicas(self.engine.arena, group, replicas)
         self.optim = optim if optim is not None else Adam(model.parameters(), lr=lr, betas=betas, eps=eps)
         self._loss = loss_fn if loss_fn is not None else ops.loss_fwd_bwd
         self.reducer = BucketedAllReduce(self.engine.arena, group, always=always_reduce, compress=grad_compress)

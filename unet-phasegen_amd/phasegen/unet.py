@@ -215,12 +215,17 @@ class UNetEngine:
 
     def _shadows(self):
         """bf16 shadows of the conv weights in the resident kernels' layout, rebuilt when the parameters have changed."""
-        if getattr(self, "_shadow_version", None) != self.arena.version:
+        # two counters: arena.version is bumped by the writers that go through the ctypes kernels (init, load, phasegen's Adam:
+        # torch cannot see those writes), arena.flat._version by every in-place write torch itself makes through a parameter
+        # view (torch.optim.Adam(model.parameters()).step(), p.copy_/add_ under no_grad, p.detach().mul_, ...) -- either one changing
+        # rebuilds the shadows.  Only a write through `p.data` (a tensor with its own version counter) still needs arena.touch().
+        ver = (self.arena.version, self.arena.flat._version)
+        if getattr(self, "_shadow_version", None) != ver:
             self._shadow = getattr(self, "_shadow", {})
             for name in self.RESIDENT_LAYERS:
                 key, kind, s, p = LAYERS[name]
                 self._shadow[name] = ops.shadow_weights(self.arena.p(key), kind == "t", s, out=self._shadow.get(name))
-            self._shadow_version = self.arena.version
+            self._shadow_version = ver
         return self._shadow
 
     def _plan_h(self, B, L):
