@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PG_VERSION 200 /* 0.2.0: precision / schedule / transform mode travel in the argument structs; no process-wide setters */
+#define PG_VERSION 300 /* 0.3.0: pg_conv_fwd_h reads its zero padding from the rows' tails and a PG_H_HEAD zero head (0.2.0: knobs in the argument structs) */
 
 enum { PG_OK = 0, PG_ERR_NULL = -1, PG_ERR_SHAPE = -2, PG_ERR_ALIGN = -3, PG_ERR_UNSUPPORTED = -4,
        PG_ERR_WORKSPACE = -5 };
@@ -98,11 +98,17 @@ int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, int32_t bufle
 
 /* ---- bf16-RESIDENT forward convolutions (BASELINE configs[4]: "bf16 MFMA convs") ----------------------------------------
  * Same two forward ops, but the operands already live in HBM as bf16: activations (B, C, pitch) whose rows are `pitch`
- * elements apart (pitch even, > L, elements [L, pitch) of every row ZERO -- allocate zero-filled once; producers never write
- * the tail), weights as a bf16 shadow of the fp32 master weights in the kernels' GEMM layout (pg_shadow_weights, rebuilt
- * whenever the masters change).  v_mfma_f32_32x32x16_bf16, fp32 accumulate.  Outputs: the fp32 result as is (y, optional: what
+ * elements apart (pitch and batch stride even, pitch > L, elements [L, pitch) of every row ZERO -- allocate zero-filled once;
+ * producers never write the tail), weights as a bf16 shadow of the fp32 master weights in the kernels' GEMM layout
+ * (pg_shadow_weights, rebuilt whenever the masters change).
+ * Zero-padding contract of x (v0.3): the kernels gather row windows as unchecked 16-byte pieces, so the convolution's zero
+ * padding is READ from memory: (1) every row's zero tail must cover what a window reaches in front of the NEXT row and behind
+ * this row's last frame (pg_conv_fwd_h_supported checks the layer's need; 40 elements cover every layer of the U-Net), and
+ * (2) the PG_H_HEAD elements (64 bytes) in front of x must be readable and zero -- for a channel slice of a larger tensor
+ * they are the previous channel's tail; a tensor of its own is allocated with that many zero elements in front.  v_mfma_f32_32x32x16_bf16, fp32 accumulate.  Outputs: the fp32 result as is (y, optional: what
  * pg_bn_fwd normalises) and / or up to two bf16 copies stored already activated for the next layer.  Geometries: the U-Net's
  * (k, stride) pairs with Cin a multiple of 32 / min(taps per phase, 32); others return PG_ERR_UNSUPPORTED (use pg_conv*_fwd). */
+#define PG_H_HEAD 32
 typedef struct pg_convh_args {
     int32_t B, Cin, Cout, Lin, Lout, k, stride, pad;
     int32_t transposed;              /* 0: nn.Conv1d forward (model.py:77-78), 1: nn.ConvTranspose1d forward (model.py:88-102) */
@@ -214,9 +220,11 @@ int pg_istft(const pg_istft_args* a, void* stream);
  * real parts, rows bins.. imaginary parts of bins 1..bins-2 (DC/Nyquist imaginary parts are ignored by an irfft).
  * pg_ola_nt: overlap-add of windowed frames given as (n_fft, frames) [n][t], any even n_fft (the reference inverts the
  * DC-dropped matrix, n_fft = 2*(bins-1) = 2046), / window-sum-square, trim n_fft/2, optional peak normalisation. */
-typedef struct pg_gl_args { int32_t bins, frames; const float* S; const float* mag; float* x; float* spec_out; } pg_gl_args;
+typedef struct pg_gl_args { int32_t bins, frames; const float* S; const float* mag; float* x; float* spec_out;
+                            int32_t n, _pad0; } pg_gl_args;       /* n clips (0 = 1): every tensor gains a leading clip axis */
 int pg_gl_project(const pg_gl_args* a, void* stream);
-typedef struct pg_ola_args { int32_t n_fft, frames, hop, normalize; const float* fr; float* audio; void* workspace; int64_t workspace_bytes; } pg_ola_args;
+typedef struct pg_ola_args { int32_t n_fft, frames, hop, normalize; const float* fr; float* audio; void* workspace; int64_t workspace_bytes;
+                             int32_t n, _pad0; } pg_ola_args;     /* n clips (0 = 1, at most 64): fr (n, n_fft, frames), audio (n, len) */
 int pg_ola_nt(const pg_ola_args* a, void* stream);   /* workspace: 256 bytes */
 
 /* preproc_mdb.py:182: x = (x - x.mean()) / x.std() over the WHOLE array (population std).  pg_moments reduces in double and

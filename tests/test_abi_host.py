@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in phasegen.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
-    assert lib.pg_version() == 200
+    assert lib.pg_version() == 300
 
 
 def test_struct_sizes_match_the_header_layout():
@@ -172,3 +172,37 @@ def test_engine_refuses_to_run_without_a_gpu():
     from phasegen.model import UNetModel
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         UNetModel(8, 16)
+
+
+def test_no_kernel_in_the_library_uses_scratch():
+    """the generic (k, s) fallback conv_t_kernel<0, 0, *> carried 296 B of scratch (73 spilled VGPRs) and
+    conv_g_raw_kernel<4, 2, 1> 2 spills.  Read every gfx950 code object out of the shipped .so and require, from the kernel
+    descriptors' notes, .private_segment_fixed_size == 0 and .vgpr_spill_count == 0 for every kernel (no GPU needed)."""
+    import shutil
+    import subprocess
+    import tempfile
+    from phasegen import _lib
+    tools = "/opt/rocm/lib/llvm/bin"
+    objdump, readelf = os.path.join(tools, "llvm-objdump"), os.path.join(tools, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        import pytest
+        pytest.skip("ROCm's llvm-objdump / llvm-readelf not installed")
+    with tempfile.TemporaryDirectory() as td:
+        so = shutil.copy(_lib.LIB_PATH, td)                       # --offloading unbundles NEXT TO its input: never in the tree
+        subprocess.run([objdump, "--offloading", so], cwd=td, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cos = [f for f in sorted(os.listdir(td)) if f.endswith("gfx950")]
+        assert len(cos) >= 9                                      # one code object per translation unit
+        kernels, bad = 0, []
+        for f in cos:
+            notes = subprocess.run([readelf, "--notes", os.path.join(td, f)], check=True, capture_output=True, text=True).stdout
+            name = None
+            for ln in notes.splitlines():
+                ln = ln.strip()
+                if ln.startswith(".name:"):
+                    name = ln.split(":", 1)[1].strip()
+                    kernels += 1
+                elif ln.startswith((".private_segment_fixed_size:", ".vgpr_spill_count:", ".sgpr_spill_count:")):
+                    k, v = ln.split(":")
+                    if int(v) != 0 and not k.startswith(".sgpr"):  # SGPR spills go to VGPR lanes, not to memory
+                        bad.append((name, k, int(v)))
+        assert kernels >= 100 and not bad, bad

@@ -36,6 +36,9 @@ GEOMS = [
     (False, 130, 260, 4, 2, 1, 29, 3), (True, 260, 130, 5, 2, 1, 14, 3), (True, 264, 132, 8, 2, 1, 29, 2),
     (True, 264, 132, 8, 1, 2, 62, 2), (True, 200, 140, 32, 2, 16, 65, 2),
     (False, 24, 40, 7, 3, 2, 50, 2), (True, 24, 40, 7, 3, 2, 17, 2),
+    # k = 5, s = 2 beyond the U-Net's own use (transposed, even channel counts): as a Conv1d, with odd channel counts (the F
+    # form then stays on the im2col kernel), with enough columns for several tiles and samples per tile
+    (False, 34, 20, 5, 2, 1, 31, 3), (False, 33, 70, 5, 2, 2, 17, 2), (True, 36, 17, 5, 2, 1, 9, 2), (True, 72, 140, 5, 2, 1, 30, 9),
 ]
 
 

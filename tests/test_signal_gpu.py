@@ -214,6 +214,29 @@ def test_griffin_lim_vs_oracle(n_fft, hop, frames, n_iter):
     assert np.array_equal(a2, a3)
 
 
+@pytest.mark.parametrize("n_fft,hop,frames,n_iter,n_clips", [(64, 16, 32, 5, 5), (2048, 512, 128, 3, 3), (256, 64, 40, 2, 70)])
+def test_griffin_lim_batch_equals_the_clips_one_by_one(n_fft, hop, frames, n_iter, n_clips):
+    """n clips cost the launches of one (STFT, projection, the 2046-point inverse GEMM and the overlap-add all
+    carry the clip axis), and clip c of the batch is BIT-IDENTICAL to the clip run alone -- no kernel reduces across clips.
+    70 clips exercise the 64-clip chunking of the overlap-add's peak words."""
+    import torch
+    from phasegen import audio
+    n = hop * (frames - 1)
+    mags = np.stack([np.abs(np.delete(signal_ref.stft(detgen.make_clip(n, seed=300 + c), n_fft, hop), 0, axis=0)) for c in range(n_clips)])
+    mags = torch.from_numpy(mags.astype(np.float32)).cuda()
+    init = torch.from_numpy(np.stack([detgen.normal(400 + c, (n,)) for c in range(n_clips)]).astype(np.float32))
+    a, s, l = audio.griffin_lim_batch(mags, n_fft, hop, n_iter, init=init)
+    assert tuple(a.shape) == (n_clips, n) and tuple(s.shape) == (n_clips, 2, n_fft // 2, frames) and tuple(l.shape) == (n_clips,)
+    for c in sorted({0, 1, n_clips // 2, n_clips - 1}):
+        a1, s1, l1 = audio.griffin_lim_batch(mags[c:c + 1], n_fft, hop, n_iter, init=init[c:c + 1])
+        assert torch.equal(a[c], a1[0]) and torch.equal(s[c], s1[0]) and torch.equal(l[c], l1[0])
+    assert float((a.abs().amax(dim=1) - 1).abs().max()) < 1e-6
+    # seeded starts: clip c of a batch draws with seed + c, so a batch reproduces single-clip calls with those seeds
+    b, _, _ = audio.griffin_lim_batch(mags[:2], n_fft, hop, n_iter, seed=11)
+    b1, _, _ = audio.griffin_lim(mags[1].cpu().numpy(), n_fft, hop, n_iter, seed=12)
+    assert np.array_equal(b[1].cpu().numpy(), b1)
+
+
 @pytest.mark.parametrize("n_fft,hop,t_slice,single", [(64, 16, 496, 0), (64, 16, 496, 1), (2048, 512, 65024, 0), (256, 64, 1001, 0)])
 def test_stft_reads_chunks_in_place(n_fft, hop, t_slice, single):
     """pg_stft_args.chunk_start / chunk_row (row N2, preproc_mdb.py:84-97): the STFT of chunks read in place from a

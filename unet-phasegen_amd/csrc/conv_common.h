@@ -24,6 +24,7 @@ struct IgemmParams {
     int LP; float inv_LP;            // G: frames of P and 1/LP
     int a_vec;                       // F: weight rows may be read as aligned float4
     int tilesM, tilesN;
+    int tn_stride;                   // columns between the origins of consecutive column tiles (= tile width; k = 5 wgrad: 255 of 256)
     float* y2; long y2_bs; float y_slope, y2_slope;   // F,T fwd: activation on store, optional second output
     float* ws;                       // stream-K partial-tile workspace: [grid][2][64][256] floats (or NULL)
     int nslab;                       // K slabs per tile
@@ -420,13 +421,16 @@ __device__ __forceinline__ void epilogue_t_pm(const IgemmParams& p, const AccT<M
     }
 }
 
+// ncap: first column that no longer belongs to this tile (the k = 5 wgrad tile holds 255 valid columns: its 256th is the next
+// tile's first).  The default never binds.
 template <int S, int MB, int NB>
-__device__ __forceinline__ void epilogue_g(const IgemmParams& p, const AccT<MB, NB>& acc, int m0, int n0, int lane, int wm, int wn) {
-    const int Ntot = p.Q * p.k;
+__device__ __forceinline__ void epilogue_g(const IgemmParams& p, const AccT<MB, NB>& acc, int m0, int n0, int lane, int wm, int wn,
+                                           int ncap = 0x7fffffff) {
+    const int Ntot = p.Q * p.k, Nlim = min(Ntot, ncap);   // row pitch of dW; first column this tile does not own
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * (NB * 32) + j * 32 + (lane & 31);
-        if (n >= Ntot) continue;
+        if (n >= Nlim) continue;
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -442,7 +446,7 @@ __device__ __forceinline__ void epilogue_g(const IgemmParams& p, const AccT<MB, 
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + wn * (NB * 32) + j * 32 + (lane & 31);
-        if (n >= Ntot) continue;
+        if (n >= Nlim) continue;
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll

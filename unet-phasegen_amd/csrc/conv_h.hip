@@ -6,39 +6,53 @@
 // Why a separate kernel: in the fp32-tensor kernels' bf16 mode (conv_raw_impl.h, BF = 1) the matrix pipe is 16x faster but
 // every operand still travels as fp32 -- per 16-deep slab a wave spends 256 cycles in MFMAs and ~580 in 36 LDS reads, 24
 // conversions and the gather issue.  Here a slab is 32 deep, and per slab a wave issues
-//   A: 4 x ds_read_b128 (weights: 8 consecutive k of a row are one aligned 16-byte read, no conversion),
-//   B: 24 x ds_read(2)_b32 + 32 x v_alignbit (activations: raw bf16 row windows; a lane's 8 consecutive taps start at an
+//   A: 8 x ds_read_b128 (weights: 8 consecutive k of a row are one aligned 16-byte read, no conversion),
+//   B: 12 x ds_read2_b32 + 16 x v_alignbit (activations: raw bf16 row windows; a lane's 8 consecutive taps start at an
 //      arbitrary ELEMENT, i.e. at a dword + 0 or 2 bytes: five dwords are read and funnel-shifted by the lane's parity),
-// for 16 MFMAs: 2.6x fewer LDS instructions and no conversion VALU per MFMA, half the LDS-DMA instructions per k.
+// for 16 MFMAs.
 //
-// Layout contract for the activation operand: rows (b, c, :) are `x_pitch` elements apart, x_pitch even, and elements
-// [L, x_pitch) of every row are ZERO (at least one): window dwords are gathered at even element offsets, so the only partly
-// valid dword is (L-1, L) for odd L, whose second half must read 0.  Producers (epilogues here, pg_bn_fwd, pg_cast_rows_bf16)
-// keep that tail zero.  K must be whole channels per slab (Q % (32 / min(taps, 32)) == 0); otherwise the caller uses the fp32-
-// tensor path.  Work decomposition, stream-K split, fixup kernels and epilogues are the shared ones (conv_common.h).
+// Layout contract for the activation operand (round 3: windows are gathered as 16-BYTE pieces, 8 elements each, with no
+// per-element range check -- the zeros of the convolution's padding are READ, not synthesised):
+//   * rows (b, c, :) are `x_pitch` elements apart, x_pitch and the batch stride even (pieces start at even elements);
+//   * elements [L, x_pitch) of every row are ZERO, and that tail is long enough for this layer (pg_conv_fwd_h_supported says
+//     so: the window of a row reaches at most `left` elements in front of it -- into the previous row's tail -- and `right`
+//     behind element L - 1; tail >= max(left, right); 40 elements cover every layer of the U-Net, ops.h_pitch);
+//   * the PG_H_HEAD (32) elements in front of x are readable and zero (row (0, 0) has no previous row's tail: ops.h_alloc
+//     puts a zero head pad in front; a channel slice of a larger tensor has the previous channel's tail there).
+// Producers (epilogues here, pg_bn_fwd, pg_cast_rows_bf16) only ever write elements [0, L) and keep the tails zero.
+// K must be whole channels per slab (Q % (32 / min(taps, 32)) == 0); otherwise the caller uses the fp32-tensor path.
+// Work decomposition, stream-K split, fixup kernels and epilogues are the shared ones (conv_common.h).
 #include "conv_common.h"
 
 namespace {
 
 constexpr int KB = 32;                    // k per slab (two MFMA k-steps of 16)
+constexpr int H_HEAD = 32;                // zero elements the caller guarantees in front of x (bytes: 64)
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// window geometry shared by the kernel and the host-side check: dwords reserved per channel window
+__host__ __device__ constexpr int h_rsd(int sc) { return sc == 1 ? 256 : 384; }
+__host__ __device__ __forceinline__ int h_round4(int v) { return (v + 3) & ~3; }
 
 template <int KW, int S, bool TKIND>
 __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
-    constexpr int TM = RBM, TN = RBN;                 // workgroup tile 128 x 256, wave tile 64 x 128
+    constexpr int TM = RBM, TN = RBN;                 // workgroup tile 128 x 256
     constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
     constexpr int TJ = KWP < 32 ? KWP : 32, NQ = 32 / TJ;
     constexpr int SC = TKIND ? 1 : S;                 // window elements per column step
-    constexpr int RSD = SC == 1 ? 192 : 384;          // dwords reserved per channel window
-    constexpr int NPC = (RSD + NT - 1) / NT;          // gather pieces per thread and window
+    constexpr int RSD = h_rsd(SC);                    // dwords reserved per channel window (a multiple of 4: 16-byte pieces)
+    constexpr int NP = NQ * RSD / 4;                  // 16-byte window pieces per slab; piece i fills dwords [4 i, 4 i + 4) of the
+    constexpr int NI = (NP + 63) / 64;                //   [channel][RSD] image -> NI wave instructions, dealt round-robin to the waves
+    constexpr int NPW = (NI + 3) / 4;                 // ... at most NPW per wave (D3: 3, D2 / U2: 2, the others 1)
     constexpr int TA = TM * 16;                       // dwords of the weight tile: 128 rows x 64 B (32 bf16)
-    constexpr int STG = TA + NQ * RSD;
+    constexpr int STG = TA + NI * 256;                // window region rounded up to whole wave instructions: lanes past NP write zeros
     // slabs per barrier: two 32-deep slabs are gathered together and multiplied one after the other where both stage pairs fit
     // 64 KB (two workgroups per CU) -- halves the barrier / gather-burst rate; a bf16 slab is only 16 MFMAs (512 cycles) per wave
     constexpr int SPB = 4 * STG * 4 <= 64 * 1024 ? 2 : 1;
     constexpr int SSTG = SPB * STG;
     static_assert(KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "taps per channel in K order");
     static_assert(2 * SSTG * 4 <= 64 * 1024, "LDS budget");
+    static_assert(RSD % 4 == 0 && TA % 4 == 0, "16-byte aligned window images");
     __shared__ __attribute__((aligned(16))) float lds[2 * SSTG];
     const int tid = threadIdx.x, lane = tid & 63;
     // waves 1 (M) x 4 (N): a wave owns ALL 128 rows of the tile and 64 of its columns (4 x 2 blocks).  The B fragments -- scalar
@@ -49,7 +63,9 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
     const int r = lane & 31, h = lane >> 5;
     const int Lcol = TKIND ? p.U : p.Ly;
     const int Ktot = p.Q * KWP, Mrows = TKIND ? p.M * S : p.M;
-    const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    // the activation descriptor starts H_HEAD elements in front of x (zero by contract): every window offset below is >= 0
+    const rsrc_t rw = make_rsrc(p.w, p.w_bytes);
+    const rsrc_t rx = make_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p.x) - H_HEAD), p.x_bytes + 2 * H_HEAD);
     const int g = logical_wg(blockIdx.x, gridDim.x, p.whole);
     const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x, p.whole);
     int pos = split_lo(sp, g);
@@ -63,12 +79,13 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
         // ---- segments (samples) of the tile and their window geometry, in DWORDS of bf16 pairs --------------------------
         // segment k holds the columns of sample b0 + k.  Its window starts at memory element pos_k (first tap of its first
         // column), loaded from the even element pe_k = pos_k - sh_k below it.  Every middle segment has the same pos (frame 0).
+        // Segment windows are whole 16-byte pieces (dword counts rounded up to 4) laid back to back: [seg 0 | full middle ... | last].
         const int nc0 = min(Lcol - t0, TN);                                       // columns of segment 0
         const int pos_first = TKIND ? p.u_off + t0 - (TJ - 1) : S * t0 - p.p;     // memory element of window element 0, segment 0
         const int pos_mid = TKIND ? p.u_off - (TJ - 1) : -p.p;                    //   ... of the later segments (frame 0)
         const int sh0 = pos_first & 1, shm = pos_mid & 1;                         // (two's complement: also right for negatives)
-        const int nd0 = (SC * (nc0 - 1) + TJ + sh0 + 1) >> 1;                     // dwords of segment 0's window
-        const int ndm = (SC * (Lcol - 1) + TJ + shm + 1) >> 1;                    //   ... of a full middle segment
+        const int nd0 = h_round4((SC * (nc0 - 1) + TJ + sh0 + 1) >> 1);           // dwords of segment 0's window
+        const int ndm = h_round4((SC * (Lcol - 1) + TJ + shm + 1) >> 1);          //   ... of a full middle segment
 
         // ---- weight-tile gather: 16-byte pieces of the K-contiguous bf16 rows, swizzled image as in the fp32 kernels ------
         int avoff[2];
@@ -77,19 +94,21 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
             const int m = m0 + dma16_row(lane, wv, e);
             avoff[e] = m < Mrows ? m * Ktot * 2 + dma16_kc(lane) * 4 : FAR;
         }
-        // ---- window gather: this thread owns window dwords v = tid + 256 e of every channel ----------------------------
-        int voff[NPC];
+        // ---- window gather: wave instruction j = wv + 4 e carries pieces 64 j .. 64 j + 63; this lane's piece i = 64 j + lane
+        // is dwords [4 pc, 4 pc + 4) of channel qi = i / (RSD / 4).  Its source is fixed for the tile up to the slab's first
+        // channel, which rides in the SGPR offset.  No range check: zeros come from the rows' tails (contract above).
+        int voff[NPW];
 #pragma unroll
-        for (int e = 0; e < NPC; ++e) {
-            const int v = tid + NT * e;
+        for (int e = 0; e < NPW; ++e) {
+            const int i = 64 * (wv + 4 * e) + lane, qi = i / (RSD / 4), d = 4 * (i - qi * (RSD / 4));
             int k, dl;
-            if (v < nd0) { k = 0; dl = v; } else { k = 1 + (v - nd0) / ndm; dl = (v - nd0) - (k - 1) * ndm; }
-            const int e0 = (k ? pos_mid - shm : pos_first - sh0) + 2 * dl;       // even memory element of this dword
+            if (d < nd0) { k = 0; dl = d; } else { k = 1 + (d - nd0) / ndm; dl = (d - nd0) - (k - 1) * ndm; }
+            const int e0 = (k ? pos_mid - shm : pos_first - sh0) + 2 * dl;       // even memory element of the piece's first dword
             const int b = b0 + k;
-            const bool ok = b < p.B && e0 >= 0 && e0 < p.Lx && k * Lcol < t0 + TN;
-            voff[e] = ok ? (b * (int)p.x_bs + e0) * 2 : FAR;
+            const bool ok = i < NP && b < p.B && k * Lcol < t0 + TN;             // the sample exists and has columns in this tile
+            voff[e] = ok ? (b * (int)p.x_bs + qi * p.x_pitch + e0 + H_HEAD) * 2 : FAR;
         }
-        // ---- fragment bases: dword and parity of window element 0 of each of this lane's 4 columns -----------------------
+        // ---- fragment bases: dword and parity of window element 0 of each of this lane's 2 column blocks -------------------
         int bdw[NBW], bsh[NBW];
 #pragma unroll
         for (int jb = 0; jb < NBW; ++jb) {
@@ -107,25 +126,14 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc.c[i][j][q] = 0.f;
 
-// Ablation hooks for dev builds (tools/abl/build_habl.sh, -DPG_HABL=n; the product build compiles them away): 1 no weight-fragment
-// reads, 2 no window reads, 3 no gathers, 4 no MFMAs, 5 = 1 + 2, 6 = 1 + 2 + 3 (pure MFMA), 7 every slab gathers slab 0 (a cache-
-// resident source), 8 weight gathers only, 9 window gathers only, 10 windows always of slab 0, 11 weights always of slab 0.
-#ifndef PG_HABL
-#define PG_HABL 0
-#endif
 #define H_ISSUE(STAGE_PTR, SLAB)                                                                              \
-    {   float* const As = (STAGE_PTR) + wv * 64; float* const Bw = (STAGE_PTR) + TA + wv * 64;               \
-        const int k0 = PG_HABL == 7 ? ((SLAB) < p.nslab ? 0 : Ktot) : (SLAB) * KB;                           \
-        if (k0 < Ktot && PG_HABL != 3 && PG_HABL != 6) {                                                     \
-            if (PG_HABL != 9)                                                                                \
-            _Pragma("unroll") for (int e = 0; e < 2; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], (PG_HABL == 11 ? 0 : k0) * 2); \
-            const int q0 = (PG_HABL == 10 ? 0 : k0) / KWP;                                                   \
-            if (PG_HABL != 8)                                                                                \
-            _Pragma("unroll") for (int qi = 0; qi < NQ; ++qi) {                                              \
-                const int sq = (q0 + qi) * p.x_pitch * 2 + (KWP > 32 ? 0 : 0);                               \
-                _Pragma("unroll") for (int e = 0; e < NPC; ++e)                                              \
-                    if (e * NT + wv * 64 < RSD) dma4s(rx, Bw + qi * RSD + e * NT, voff[e], sq);              \
-            }                                                                                                \
+    {   float* const As = (STAGE_PTR) + wv * 64; float* const Bw = (STAGE_PTR) + TA;                         \
+        const int k0 = (SLAB) * KB;                                                                          \
+        if (k0 < Ktot) {                                                                                     \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], k0 * 2); \
+            const int sq = (k0 / KWP) * p.x_pitch * 2;                                                       \
+            _Pragma("unroll") for (int e = 0; e < NPW; ++e)                                                  \
+                if (wv + 4 * e < NI) dma16s(rx, Bw + 256 * (wv + 4 * e), voff[e], sq);                       \
         }                                                                                                    \
     }
 
@@ -139,11 +147,9 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
                 _Pragma("unroll") for (int s = 0; s < 2; ++s) {      /* MFMA k-steps: k = 16 s + 8 h + (0 .. 7) */ \
                     s16x8 a[MBW], b[NBW];                                                                    \
                     _Pragma("unroll") for (int i = 0; i < MBW; ++i)                                          \
-                        if (PG_HABL == 1 || PG_HABL == 5 || PG_HABL == 6) a[i] = (s16x8)(short)(lane + i);   \
-                        else a[i] = __builtin_bit_cast(s16x8, *reinterpret_cast<const f32x4*>(ap + i * 32 * 16 + (((2 * s + h) ^ sw) << 2))); \
+                        a[i] = __builtin_bit_cast(s16x8, *reinterpret_cast<const f32x4*>(ap + i * 32 * 16 + (((2 * s + h) ^ sw) << 2))); \
                     _Pragma("unroll") for (int jb = 0; jb < NBW; ++jb) {                                     \
                         unsigned o[4];                                                                       \
-                        if (PG_HABL == 2 || PG_HABL == 5 || PG_HABL == 6) { o[0] = o[1] = o[2] = o[3] = 0x3f803f80u + lane; } else \
                         if (TJ >= 8) {                                                                       \
                             /* channel / first tap of this lane's 8 k:  TJ 32: (0, 16 s + 8 h)  16: (s, 8 h)  8: (2 s + h, 0) */ \
                             const int qi = TJ == 32 ? 0 : (TJ == 16 ? s : 2 * s + h);                        \
@@ -166,8 +172,7 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
                     }                                                                                        \
                     _Pragma("unroll") for (int i = 0; i < MBW; ++i)                                          \
                         _Pragma("unroll") for (int jb = 0; jb < NBW; ++jb)                                   \
-                            if (PG_HABL == 4) acc.c[i][jb][0] += (float)(a[i][0] ^ b[jb][0]);                \
-                            else acc.c[i][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[jb]), acc.c[i][jb], 0, 0, 0); \
+                            acc.c[i][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[jb]), acc.c[i][jb], 0, 0, 0); \
                 }                                                                                            \
             }
 
@@ -203,24 +208,36 @@ hipError_t launch1(const IgemmParams& p, int grid, hipStream_t st) {
 
 }  // namespace
 
-// window dwords per channel that the kernel reserves / needs for this problem (host-side mirror of the kernel's geometry)
+// Host-side mirror of the kernel's window geometry: do the windows of every possible tile fit the reserved dwords, and is the
+// zero tail of the caller's rows long enough for the unchecked 16-byte window pieces (contract at the top of this file)?
 bool pgconv::h_supported(int kind, const IgemmParams& p) {
     const bool t = kind == KIND_T;
     if (kind == KIND_G) return false;
     if (t) { if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 5 && p.s == 2))) return false; }
     else if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
     const int kwp = t ? pg_shadow_taps(p.k, p.s) : p.k, tj = kwp < 32 ? kwp : 32, nq = 32 / tj, sc = t ? 1 : p.s;
-    if (p.Q % nq || (p.x_pitch & 1) || p.x_pitch <= p.Lx) return false;
-    const int lcol = t ? p.U : p.Ly, rsd = sc == 1 ? 192 : 384;
+    if (p.Q % nq || (p.x_pitch & 1) || (p.x_bs & 1) || p.x_pitch <= p.Lx) return false;
+    const int lcol = t ? p.U : p.Ly, rsd = h_rsd(sc);
+    const int pos_mid = t ? p.u_off - (tj - 1) : -p.p, shm = pos_mid & 1;
+    const int ndm = h_round4((sc * (lcol - 1) + tj + shm + 1) >> 1);
+    // elements of a row's neighbourhood a window piece can touch: [pos_mid - shm, pos_mid - shm + 2 ndm) for a sample's first
+    // column at frame 0; a first segment that starts at column t0 ends no later (its window is the same one cut at t0, rounded
+    // up to a piece: + 6 elements at most)
+    const int left = pos_mid - shm < 0 ? -(pos_mid - shm) : 0;
+    const int right = pos_mid - shm + 2 * ndm + 6 - p.Lx;
+    const int tail = p.x_pitch - p.Lx;
+    if (left > H_HEAD || tail < left || tail < right) return false;
     // the kernel lays the samples' windows out back to back (segment 0, full middle segments, last partial one): the worst
     // first-column position t0 must fit the reserved dwords
-    const int ndm = (sc * (lcol - 1) + tj + 2) >> 1;
     int need = 0;
     for (int t0 = 0; t0 < lcol; ++t0) {
         const int nc0 = lcol - t0 < RBN ? lcol - t0 : RBN, rem = RBN - nc0;
+        const int sh0 = (pos_mid + sc * t0) & 1;
         int nmid = rem / lcol, nlast = rem - nmid * lcol;                        // full middle samples, columns of the last one
         if (1 + nmid + (nlast ? 1 : 0) > p.B) { nlast = 0; if (1 + nmid > p.B) nmid = p.B - 1; }   // only B samples exist
-        const int n = ((sc * (nc0 - 1) + tj + 2) >> 1) + nmid * ndm + (nlast ? (sc * (nlast - 1) + tj + 2) >> 1 : 0);
+        // (the last, partial segment is READ up to its last column's taps only, but its pieces are issued like a full one's:
+        //  what must fit is the dwords that are read)
+        const int n = h_round4((sc * (nc0 - 1) + tj + sh0 + 1) >> 1) + nmid * ndm + (nlast ? (sc * (nlast - 1) + tj + shm + 2) >> 1 : 0);
         if (n > need) need = n;
     }
     return need <= rsd;

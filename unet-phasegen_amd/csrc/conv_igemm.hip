@@ -66,12 +66,14 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
     }
     // the epilogues place block (0, 0) of wave (wm, wn) at m0 + wm * 32, n0 + wn * 32: shift the origin to block (bi, bj)
     const int m0 = (tile / p.tilesN) * ((4 / WN) * 32 * MB) + wm * (MB - 1) * 32 + bi * 32;
-    const int n0 = (tile % p.tilesN) * (WN * 32 * NB) + wn * (NB - 1) * 32 + bj * 32;
+    // column tiles are p.tn_stride columns apart: the tile width, except the k = 5 wgrad's 255 (51 whole channels) of 256
+    const int nt0 = (tile % p.tilesN) * p.tn_stride;
+    const int n0 = nt0 + wn * (NB - 1) * 32 + bj * 32;
     if (KIND == 0) epilogue_f<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
     else if (KIND == 3)       // stride-2 raw T kernels (phase-major rows): block row bi is phase bi of the wave's 32 output channels
-        epilogue_t_pm<1, 1>(p, acc, (tile / p.tilesN) * ((4 / WN) * 16 * MB) + wm * 32, (tile % p.tilesN) * (WN * 32 * NB) + wn * (NB * 32) + bj * 32, lane, bi);
+        epilogue_t_pm<1, 1>(p, acc, (tile / p.tilesN) * ((4 / WN) * 16 * MB) + wm * 32, nt0 + wn * (NB * 32) + bj * 32, lane, bi);
     else if (KIND == 1) epilogue_t<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
-    else epilogue_g<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
+    else epilogue_g<0, 1, 1>(p, acc, m0, n0, lane, wm, wn, nt0 + p.tn_stride);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -148,18 +150,22 @@ int pick_grid(long tiles, int nslab, IgemmParams& p, long ws_bytes, int mode, in
 }
 
 // raw-window kernels: supported (k, s) pairs and the window-length bound
+// k = 5, s = 2 runs the raw-window kernels as a virtual k = 8 (conv_raw_impl.h): taps of the weight image per (row, channel)
+inline int virtual_k(int k, int s) { return (k == 5 && s == 2) ? 8 : k; }
+
 bool raw_supported(Kind kind, const IgemmParams& p, const Knobs& kn, int tn = RBN) {
     if (kn.no_raw == 1) return false;
     int kwp, sc, lcol;
+    const bool k5 = p.k == 5 && p.s == 2;
     if (kind == KIND_F) {
-        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
-        kwp = p.k; sc = p.s; lcol = p.Ly;
+        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || (k5 && p.Q % 2 == 0))) return false;
+        kwp = virtual_k(p.k, p.s); sc = p.s; lcol = p.Ly;       // (k = 5: a slab is two whole channels; an odd channel count stays on im2col)
     } else if (kind == KIND_T) {
-        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
-        kwp = p.k / p.s; sc = 1; lcol = p.U;
+        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || k5)) return false;
+        kwp = virtual_k(p.k, p.s) / p.s; sc = 1; lcol = p.U;
     } else {
         // a 16-element slab of (b, i) may run over at most ONE sample boundary in the raw-window wgrad kernel
-        return p.LP >= 16 && ((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2));
+        return p.LP >= 16 && ((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || k5);
     }
     const int tj = kwp < 16 ? kwp : 16;
     const int nseg_max = (lcol - 1 + tn - 1) / lcol + 1;
@@ -177,12 +183,17 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     const bool tall = kind != KIND_G && kn.no_raw == 0 && kn.no_tall == 0 && (cols_tall * 100 <= cols_wide * 97 || !raw) &&
                       raw_supported(kind, p, kn, RBN / 2);
     if (tall) raw = true;
-    const int bm = tall ? 2 * RBM : (raw ? RBM : BM), bn = tall ? RBN / 2 : (raw ? RBN : BN);
+    const int bm = tall ? 2 * RBM : (raw ? RBM : BM);
+    int bn = tall ? RBN / 2 : (raw ? RBN : BN);
+    const bool k5 = raw && p.k == 5 && p.s == 2;
+    if (k5 && kind == KIND_G) bn = (RBN / 5) * 5;               // wgrad: a column tile is 51 whole channels x 5 taps = 255 columns (+ 1 idle)
+    if (k5 && kind != KIND_G) Ktot = (long)p.Q * (kind == KIND_T ? 4 : 8);   // F / T: K runs over the virtual taps
+    p.tn_stride = bn;
     p.tilesM = (int)((rows + bm - 1) / bm);
     p.tilesN = (int)((cols + bn - 1) / bn);
     p.nslab = (int)((Ktot + BK - 1) / BK);
     const long tiles = (long)p.tilesM * p.tilesN;
-    if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");   // the fixup launches 8 workgroups per tile
+    if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0 || cols + bn >= 0x7fffffffL) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");   // the fixup launches 8 workgroups per tile
     const int grid = pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended);
     // ranges made of whole tiles (grid == tiles, or a grid that divides the tile count) leave nothing for the fixup
     const bool split = grid != tiles && !(tiles % grid == 0);
@@ -442,6 +453,7 @@ static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query) {
     const long rows = tr ? (long)p.M * p.s : p.M, cols = (long)p.B * (tr ? p.U : p.Ly), Ktot = (long)p.Q * kwp;
     p.tilesM = (int)((rows + RBM - 1) / RBM);
     p.tilesN = (int)((cols + RBN - 1) / RBN);
+    p.tn_stride = RBN;
     p.nslab = (int)(Ktot / 32);
     p.ws = (float*)a->workspace;
     const long tiles = (long)p.tilesM * p.tilesN;

@@ -100,8 +100,10 @@ __global__ __launch_bounds__(NT, 2) void conv_f_kernel(const IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------
 // T kernel.  GEMM rows m' = o*s + phi, K = (q, jj) with KJ = ceil(k/s) taps per phase, N = (b, u).
 // ------------------------------------------------------------------------------------------------------------
+// (the runtime-(k, s) instantiation carries 16 more per-row registers -- phi_of -- than the specialised ones and used to spill
+// 73 VGPRs at two waves per SIMD: it is built for one, the generic fallback's speed not being the point)
 template <int KW, int S, int BF>
-__global__ __launch_bounds__(NT, 2) void conv_t_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(NT, (KW == 0 ? 1 : 2)) void conv_t_kernel(const IgemmParams p) {
     const int kw_ = KW ? KW : p.k, s_ = S ? S : p.s;
     const int KJ = (kw_ + s_ - 1) / s_;
     const int Ktot = p.Q * KJ, Ntot = p.B * p.U, Mrows = p.M * s_;

@@ -16,13 +16,26 @@ namespace {
 // apart).  The tile is made wide on the activation side, where bytes are now cheap: per slab 8 KB of weights plus ~1-2 KB
 // of activations feed 128x256x16 MACs -- 60 % fewer global->LDS bytes per MFMA than the 256x128 im2col tiling.
 // Supported when the taps per channel in K order (F: k, T: k/s) are 4, 8, 16 or 32 and the windows fit RS floats;
-// everything else (k = 5, generic) stays on the im2col kernels.
+// generic (k, s) stays on the im2col kernels.
+//
+// k = 5, s = 2 (the innermost up-conv, model.py:94-95: k_size + 1) runs here as a VIRTUAL k = 8 (round 3): the weight tile is
+// loaded as if every (row, channel) had 8 taps -- 16-byte pieces at the real 20-byte row pitch, so floats 5..7 of a chunk
+// pair are the first taps of the NEXT weight row -- and the k positions of the three virtual taps are never multiplied: the
+// fp32 path skips their MFMAs (v_mfma_f32_32x32x2_f32 takes one k per lane half, and both halves of such an MFMA carry a
+// virtual tap: T form 6 of 16 per column block, F form 3 of 8), the bf16 modes zero the fragment elements.  MFMA work is
+// exactly the algorithmic 5/8 of the virtual problem, i.e. 1.0x; only the gathers and fragment reads pay for 8 taps.
 // ================================================================================================================
 // ds_read_b32-based B fragments: lane (column block jb, column r, half h) needs k = 8h .. 8h+7 of the slab, i.e.
 // (channel qi, tap tau) = divmod(8h + i, TJ); the element lives at  qi*RS + bbase[jb] +/- tau.
 struct RawFrags { f32x4 a[2][2]; float b[4][8]; };
 
-template <int TJ, bool DESC, int RS, bool PM>
+// K5: 0 = real taps only; 1 = T form of k = 5 on the phase-major image (taps 5, 6, 7 of each 8 are virtual);
+//     2 = F form of k = 5 (k = 8 h + i: taps i = 5, 6, 7 are virtual)
+template <int K5> __device__ __forceinline__ constexpr bool k5_virtual(int row_block, int kk) {
+    return K5 == 1 ? (row_block == 0 ? (kk & 3) == 3 : (kk & 3) >= 2) : (K5 == 2 ? kk >= 5 : false);
+}
+
+template <int TJ, bool DESC, int RS, bool PM, int K5, bool ZERO_VIRTUAL>
 __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
                                                const int (&bbase)[4], float slopeA, float slopeB, RawFrags& f) {
     const int r = lane & 31, h = lane >> 5;
@@ -74,6 +87,13 @@ __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, con
 #pragma unroll
                 for (int v = 0; v < 4; ++v) f.a[i][c][v] = act_apply(f.a[i][c][v], slopeA);
     }
+    if (K5 && ZERO_VIRTUAL) {       // bf16 modes (one MFMA takes all 16 k): the virtual taps' weights -- the next row's -- become 0
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                if (k5_virtual<K5>(i, kk)) f.a[i][kk >> 2][kk & 3] = 0.f;
+    }
     if (slopeB != 1.0f) {
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
@@ -82,24 +102,26 @@ __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, con
     }
 }
 
-template <int BF>
+template <int BF, int K5>
 __device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
     if (BF) { mfma_low_2x4<BF>(f.a, f.b, acc); return; }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            if (k5_virtual<K5>(i, kk)) continue;       // both lane halves of this MFMA hold a virtual tap of k = 5: never multiplied
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk >> 2][kk & 3], f.b[j][kk], acc.c[i][j], 0, 0, 0);
+        }
 }
 
-template <int TJ, bool DESC, int RS, int BF, bool PM>
+template <int TJ, bool DESC, int RS, int BF, bool PM, int K5>
 __device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
                                              const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
     RawFrags f;
-    raw_load_frags<TJ, DESC, RS, PM>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
-    raw_mfma<BF>(f, acc);
+    raw_load_frags<TJ, DESC, RS, PM, K5, BF != 0>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
+    raw_mfma<BF, K5>(f, acc);
 }
 
 // TKIND false: F (conv fwd / convT dgrad, taps ascend with stride s between columns)
@@ -112,7 +134,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     constexpr int TM = WN == 2 ? RBM : 2 * RBM, TN = WN == 2 ? RBN : RBN / 2;   // workgroup tile
     constexpr int TA = TM * BK;                       // floats of the weight tile (8 / 16 KB)
     constexpr int AE4 = TM / 16, AE16 = TM / 64;      // dword / 16-byte gather pieces per thread for the weight tile
-    constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
+    constexpr int KWV = KW == 5 ? 8 : KW;             // taps per (row, channel) of the weight tile image: k = 5 is a virtual 8
+    constexpr int K5 = KW == 5 ? (TKIND ? 1 : 2) : 0;
+    constexpr int KWP = TKIND ? KWV / S : KWV;        // taps per channel in K order
     constexpr int TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ;
     constexpr int SC = TKIND ? 1 : S;                 // window positions per column step
     constexpr int RG = raw_gap(TJ);                   // gap between the windows of consecutive samples
@@ -125,7 +149,8 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     // faster with one (146 vs 143 TFLOP/s); the F form and the k = 8 kernels gain 1-5 % from two
     constexpr int SPB = (4 * STG * 4 <= 64 * 1024 && !(TKIND && KW == 32)) ? 2 : 1;
     static_assert(KWP == 2 || KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "raw-window kernels need 2/4/8/16/32 taps per channel");
-    static_assert(!TKIND || KW % S == 0, "T raw kernel needs s | k");
+    static_assert(!TKIND || KWV % S == 0, "T raw kernel needs s | k");
+    static_assert(KW != 5 || S == 2, "k = 5 is built for stride 2 only");
     __shared__ __attribute__((aligned(16))) float lds[2 * SPB * STG];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = WN == 2 ? wv >> 1 : wv, wn = WN == 2 ? wv & 1 : 0;
@@ -176,12 +201,13 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
 #pragma unroll
             for (int e = 0; e < AE4; ++e) {
                 const int m = m0 + dma_row(lane, wv, e);
-                aoff[e] = (!p.a_vec && m < p.M) ? (m * Ktot + kt) * 4 : FAR;
+                aoff[e] = (!K5 && !p.a_vec && m < p.M) ? (m * Ktot + kt) * 4 : FAR;
             }
 #pragma unroll
             for (int e = 0; e < AE16; ++e) {
                 const int m = m0 + dma16_row(lane, wv, e);
-                avoff[e] = m < p.M ? (m * Ktot + dma16_kc(lane)) * 4 : FAR;
+                const int kc = dma16_kc(lane);      // k = 5: chunk kc of the slab = floats (kc & 7) .. + 3 of channel kc >> 3, rows 5 Q floats apart
+                avoff[e] = m < p.M ? (K5 ? (m * p.Q * 5 + (kc >> 3) * 5 + (kc & 7)) * 4 : (m * Ktot + kc) * 4) : FAR;
             }
         }
         // --- window gather constants: thread owns window positions v = tid + 256 e --------------------------------
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
                 const int sa = (k0 / KWP) * wq * 4;                                                       \
                 _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], sa); \
             } else {     /* F: 16-byte pieces always (they only need dword alignment); no branch on a_vec here */ \
-                _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], k0 * 4); \
+                _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16s(rw, As + wv * 192 + e * 1024, avoff[e], K5 ? (k0 >> 3) * 20 : k0 * 4); \
             }                                                                                             \
             const int fq0 = k0 / KWP, ft0 = k0 - fq0 * KWP;              /* ft0 = 16 only for the odd slabs of 32-tap channels */ \
             /* pieces that every tile needs (the shortest window is SC*(TN-1)+TJ floats) issue without the per-wave check; */ \
@@ -284,6 +310,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             const int kk = k0 + kt, q = kk / KWP, jj = kk - q * KWP;                                      \
             const int wo = kok ? (q * wq + S * jj) * 4 : OOB;                                             \
             _Pragma("unroll") for (int e = 0; e < AE4; ++e) dma4(rw, As + e * 256, aoff[e] + wo);         \
+        } else if (K5) {     /* F form of k = 5 (Q even: every slab inside K is whole): only slabs past K come here */ \
+            const int kv = kok ? (k0 >> 3) * 20 : OOB;                                                    \
+            _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16(rw, As + wv * 192 + e * 1024, avoff[e] + kv); \
         } else if (p.a_vec) {                                                                             \
             const int kv = (k0 + dma16_kc(lane) < Ktot) ? k0 * 4 : OOB;                                   \
             _Pragma("unroll") for (int e = 0; e < AE16; ++e) dma16(rw, As + wv * 192 + e * 1024, avoff[e] + kv); \
@@ -323,9 +352,9 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             for (int hf = 0; hf < SPB; ++hf) RAW_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, (sl + SPB + hf) * BK)
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(1)
-            mma_slab_raw<TJ, TKIND, RS, BF, PM>(lds + cur * SSTG, lds + cur * SSTG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+            mma_slab_raw<TJ, TKIND, RS, BF, PM, K5>(lds + cur * SSTG, lds + cur * SSTG + TA, lane, wm, bbase, slopeA, slopeB, acc);
             if (SPB == 2 && sl + 1 < se)
-                mma_slab_raw<TJ, TKIND, RS, BF, PM>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+                mma_slab_raw<TJ, TKIND, RS, BF, PM, K5>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + TA, lane, wm, bbase, slopeA, slopeB, acc);
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(2)
             __syncthreads();
@@ -365,9 +394,11 @@ hipError_t launch_raw_ft_wn(int kind, const IgemmParams& p, int grid, hipStream_
         if (p.k == 32) return launch_raw<32, 2, false, WN>(p, grid, st, prec);
         if (p.k == 8 && p.s == 1) return launch_raw<8, 1, false, WN>(p, grid, st, prec);
         if (p.k == 8) return launch_raw<8, 2, false, WN>(p, grid, st, prec);
+        if (p.k == 5) return launch_raw<5, 2, false, WN>(p, grid, st, prec);
         return launch_raw<4, 2, false, WN>(p, grid, st, prec);
     }
     if (p.k == 32) return launch_raw<32, 2, true, WN>(p, grid, st, prec);
+    if (p.k == 5) return launch_raw<5, 2, true, WN>(p, grid, st, prec);
     if (p.k == 4) return launch_raw<4, 2, true, WN>(p, grid, st, prec);
     if (p.s == 1) return launch_raw<8, 1, true, WN>(p, grid, st, prec);
     return launch_raw<8, 2, true, WN>(p, grid, st, prec);

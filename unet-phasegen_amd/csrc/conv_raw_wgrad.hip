@@ -5,7 +5,7 @@ namespace {
 
 // ----------------------------------------------------------------------------------------------------------------
 // Raw-window variant of the G (wgrad) kernel: dW[m][(q,j)] = sum_{k=(b,i)} P[b,m,i] * Q[b,q,s*i+j-p], tile 128 (m) x 256
-// ((q,j) columns = 256/k whole channels).  Per slab of 16 consecutive (b,i) the columns of one channel are k shifted
+// ((q,j) columns = 256/k whole channels; k = 5: 51 channels = 255 columns, the 256th is idle and column tiles are 255 apart).  Per slab of 16 consecutive (b,i) the columns of one channel are k shifted
 // views of the SAME piece of Q's row: positions s*i0 - p + [0, 15 s + k).  That window is staged once per channel
 // (LDS image [sub][channel][WLP], sub 1 only filled when the slab runs over the end of sample b into b+1) and the
 // B fragment of column (q,j), slab element kl is read at  q*WLP + j + s*kl  (+ a wave-uniform shift for kl past the
@@ -14,10 +14,13 @@ namespace {
 template <int KW, int S> struct GRaw {
     static constexpr int WL = 15 * S + KW;                                   // window floats actually read
     static constexpr int WLP = (KW == 32) ? 64 : (KW == 8 ? (S == 1 ? 24 : 40) : 36);   // padded; keeps reads conflict-free
-    static constexpr int NQT = RBN / KW;                                      // channels per tile
+    static constexpr int NQT = RBN / KW;                                      // whole channels per tile (k = 5: 51, one idle column)
+    static constexpr int TNV = NQT * KW;                                      // columns of a tile that exist; also the tile pitch in N
     static constexpr int SUB = NQT * WLP;                                     // floats per sub-window set
+    static constexpr int SUBS = (SUB + 63) / 64 * 64;                         // its slot: a dword gather instruction writes 64 floats,
+                                                                              //   also from lanes past SUB (k = 5: 1836 -> 1856)
     static constexpr int NE = (SUB + NT - 1) / NT;                            // gather pieces per thread and sub-window
-    static constexpr int STG = RTILE_A + 2 * SUB;                             // floats per LDS stage
+    static constexpr int STG = RTILE_A + 2 * SUBS;                            // floats per LDS stage
     static_assert(WL <= WLP, "window does not fit its slot");
 };
 
@@ -39,8 +42,8 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
     while (pos < pos_end) {
         const int tile = pos / p.nslab, sb = pos - tile * p.nslab;
         const int se = min(p.nslab, sb + (pos_end - pos));
-        const int m0 = (tile / p.tilesN) * RBM, n0 = (tile % p.tilesN) * RBN;
-        const int qbase = n0 / KW;
+        const int m0 = (tile / p.tilesN) * RBM, n0 = (tile % p.tilesN) * C::TNV;
+        const int qbase = (tile % p.tilesN) * C::NQT;
 
         int aoff[8];                                   // P[b][m][i]: byte offset of row m (this thread's k column added per slab)
 #pragma unroll
@@ -48,17 +51,28 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
             const int m = m0 + dma_row(lane, wv, e);
             aoff[e] = m < p.M ? m * p.LP * 4 : FAR;
         }
-        int choff[C::NE], vv[C::NE];                   // window element owned by this thread: channel byte offset, v - pad
+        // window element idx = tid + NT e owned by this thread on the general (per-element) path: channel byte offset and v - pad,
+        // held in registers -- short samples (30 frames: every other slab runs over a sample boundary) take that path often.  Only
+        // the bf16-mode k = 4 / k = 5 kernels, which would spill, recompute them where used (RECOMP; the opaque copy of tid keeps the
+        // compiler from hoisting the values out of the slab loop again).
+        constexpr bool RECOMP = KW <= 5 && BF != 0;
+        int choff[RECOMP ? 1 : C::NE], vv[RECOMP ? 1 : C::NE];
+        if (!RECOMP) {
 #pragma unroll
-        for (int e = 0; e < C::NE; ++e) {
-            const int idx = tid + NT * e, ql = idx / C::WLP, v = idx - ql * C::WLP;
-            choff[e] = (idx < C::SUB && qbase + ql < p.Q) ? (qbase + ql) * p.Lx * 4 : FAR;
-            vv[e] = v - p.p;
+            for (int e = 0; e < C::NE; ++e) {
+                const int idx = tid + NT * e, ql = idx / C::WLP, v = idx - ql * C::WLP;
+                choff[e] = (idx < C::SUB && qbase + ql < p.Q) ? (qbase + ql) * p.Lx * 4 : FAR;
+                vv[e] = v - p.p;
+            }
         }
+#define GRAW_CHOFF(e) (RECOMP ? ({ int t_ = tid; asm volatile("" : "+v"(t_)); const int idx_ = t_ + NT * (e), ql_ = idx_ / C::WLP; \
+                                  (idx_ < C::SUB && qbase + ql_ < p.Q) ? (qbase + ql_) * p.Lx * 4 : FAR; }) : choff[RECOMP ? 0 : (e)])
+#define GRAW_VV(e) (RECOMP ? ({ int t_ = tid; asm volatile("" : "+v"(t_)); const int idx_ = t_ + NT * (e); idx_ - (idx_ / C::WLP) * C::WLP - p.p; }) \
+                           : vv[RECOMP ? 0 : (e)])
         // Slabs that lie inside one sample (all but one in LP/16) read the P tile as two 16-byte pieces per thread: 16 consecutive
         // frames of a row are contiguous (16-byte LDS-DMA only needs dword alignment, tools/probe/ldsdma16.hip), the (sample, frame)
         // of the slab is wave-uniform and rides in the SGPR offset.  Enabled where registers allow.
-        constexpr bool FASTP = BF != 2 && !(KW == 4 && BF != 0);   // (the bf16-mode k = 4 kernels are at the register limit)
+        constexpr bool FASTP = BF != 2 && !(KW <= 5 && BF != 0);   // (the bf16-mode k = 4 / k = 5 kernels are at the register limit)
         constexpr bool FASTW = FASTP && KW != 4;          // SGPR-offset window gathers: k = 4 has 9 pieces per thread, their offsets spill
         // window inside the row (the common case): the whole window set of the tile loads as 16-byte pieces -- piece pc =
         // floats [4 pc, 4 pc + 4) of the [channel][WLP] image (WLP is a multiple of 4, so a piece never straddles channels;
@@ -119,15 +133,15 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
         const int sb0 = gb < p.B ? gb * xbs4 : -NEVER, sb1 = (kc < 16 && gb + 1 < p.B) ? (gb + 1) * xbs4 : -NEVER; \
         _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                               \
             if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) {                                    \
-                const int ps = S * gi + vv[e];                                                            \
-                dma4(rx, Bw + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb0 >= 0) ? sb0 + choff[e] + ps * 4 : FAR); \
+                const int ps = S * gi + GRAW_VV(e);                                                       \
+                dma4(rx, Bw + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb0 >= 0) ? sb0 + GRAW_CHOFF(e) + ps * 4 : FAR); \
             }                                                                                             \
         }                                                                                                 \
         if (kc < 16) {                                 /* slab runs into the next sample: second sub-window */ \
             _Pragma("unroll") for (int e = 0; e < C::NE; ++e) {                                           \
                 if ((e + 1) * NT <= C::SUB || e * NT + wv * 64 < C::SUB) {                                                          \
-                    const int ps = vv[e];                                                                 \
-                    dma4(rx, Bw + C::SUB + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb1 >= 0) ? sb1 + choff[e] + ps * 4 : FAR); \
+                    const int ps = GRAW_VV(e);                                                            \
+                    dma4(rx, Bw + C::SUBS + e * NT, ((unsigned)ps < (unsigned)p.Lx && sb1 >= 0) ? sb1 + GRAW_CHOFF(e) + ps * 4 : FAR); \
                 }                                                                                         \
             }                                                                                             \
         }                                                                                                 \
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
                     // addresses, which cost the common path 60 VALU and left its 32 reads unpaired)
                     typedef const volatile __attribute__((address_space(3))) float* lds_vptr;
                     const lds_vptr Bv = (lds_vptr)Bw;
-                    const int shift = C::SUB - S * kc_cur;
+                    const int shift = C::SUBS - S * kc_cur;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int d = (8 * h + i >= kc_cur) ? shift : 0;
@@ -209,7 +223,9 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
         }
         PG_STAMP_FLUSH
 #undef GRAW_ISSUE
-        if (sb == 0 && se == p.nslab) epilogue_g<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
+#undef GRAW_CHOFF
+#undef GRAW_VV
+        if (sb == 0 && se == p.nslab) epilogue_g<S, 2, 4>(p, acc, m0, n0, lane, wm, wn, n0 + C::TNV);
         else store_partial(p.ws, g, slot, acc, tid);
         pos += se - sb;
         slot = 1;
@@ -230,5 +246,6 @@ hipError_t pgconv::launch_raw_g(const IgemmParams& p, int grid, hipStream_t st, 
     if (p.k == 32) return launch_g_raw<32, 2>(p, grid, st, prec);
     if (p.k == 8 && p.s == 1) return launch_g_raw<8, 1>(p, grid, st, prec);
     if (p.k == 8) return launch_g_raw<8, 2>(p, grid, st, prec);
+    if (p.k == 5) return launch_g_raw<5, 2>(p, grid, st, prec);
     return launch_g_raw<4, 2>(p, grid, st, prec);
 }

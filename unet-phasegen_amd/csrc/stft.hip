@@ -553,25 +553,34 @@ __global__ __launch_bounds__(256) void istft_normalize_kernel(float* audio, int 
 }
 
 // Griffin-Lim projection onto the target magnitudes: keep the phase of S, impose mag (utils.py:122-124)
+// (blockIdx.y = clip: S / spec_out (n, 2, bins, frames), mag (n, bins, frames), x (n, 2 bins - 2, frames))
 __global__ __launch_bounds__(256) void gl_project_kernel(const pg_gl_args a) {
     const long total = (long)a.bins * a.frames;
+    const float* S = a.S + 2 * total * blockIdx.y;
+    const float* mag = a.mag + total * blockIdx.y;
+    float* x = a.x + (long)(2 * a.bins - 2) * a.frames * blockIdx.y;
+    float* so = a.spec_out ? a.spec_out + 2 * total * blockIdx.y : nullptr;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int r = (int)(e / a.frames), t = (int)(e - (long)r * a.frames);
-        float re = a.S[e], im = a.S[total + e];
+        float re = S[e], im = S[total + e];
         pg_complex_from_parts(re, im);                      // np.angle on re + 1j*im
-        const float mod = hypotf(re, im), m = a.mag[e];
+        const float mod = hypotf(re, im), m = mag[e];
         const float c = mod > 0.f ? re / mod : 1.f, s = mod > 0.f ? im / mod : 0.f;   // angle(0) = 0
         const float nr = m * c, ni = m * s;
-        if (a.spec_out) { a.spec_out[e] = nr; a.spec_out[total + e] = ni; }
-        a.x[e] = nr;
-        if (r >= 1 && r <= a.bins - 2) a.x[(long)(a.bins + r - 1) * a.frames + t] = ni;
+        if (so) { so[e] = nr; so[total + e] = ni; }
+        x[e] = nr;
+        if (r >= 1 && r <= a.bins - 2) x[(long)(a.bins + r - 1) * a.frames + t] = ni;
     }
 }
 
 // overlap-add of (n_fft, frames)-major windowed frames, any even n_fft
-__global__ __launch_bounds__(256) void ola_nt_kernel(const pg_ola_args a, unsigned* peak) {
+// (blockIdx.y = clip: fr (n, n_fft, frames), audio (n, len), one peak word per clip)
+__global__ __launch_bounds__(256) void ola_nt_kernel(pg_ola_args a, unsigned* peak) {
     __shared__ float scratch[16];
     const int N = a.n_fft, len = a.hop * (a.frames - 1);
+    a.fr += (long)N * a.frames * blockIdx.y;
+    a.audio += (long)len * blockIdx.y;
+    peak += blockIdx.y;
     float mx = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
         const int ip = i + (N >> 1);
@@ -689,9 +698,10 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
 
 extern "C" int pg_gl_project(const pg_gl_args* a, void* stream) {
     if (!a || !a->S || !a->mag || !a->x) return pg_fail(PG_ERR_NULL, "gl_project: S, mag, x required");
-    if (a->bins < 3 || a->frames <= 0) return pg_fail(PG_ERR_SHAPE, "gl_project: bad sizes");
+    if (a->bins < 3 || a->frames <= 0 || a->n < 0 || a->n > 65535) return pg_fail(PG_ERR_SHAPE, "gl_project: bad sizes");
+    const unsigned n = a->n ? (unsigned)a->n : 1u;          // n = 0: one clip (the v0.2 layout of the struct)
     long blocks = ((long)a->bins * a->frames + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gl_project_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(gl_project_kernel, dim3((unsigned)blocks, n), dim3(256), 0, (hipStream_t)stream, *a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
 }
@@ -699,15 +709,17 @@ extern "C" int pg_gl_project(const pg_gl_args* a, void* stream) {
 extern "C" int pg_ola_nt(const pg_ola_args* a, void* stream) {
     if (!a || !a->fr || !a->audio || !a->workspace) return pg_fail(PG_ERR_NULL, "ola_nt: fr, audio, workspace required");
     if (a->n_fft < 4 || (a->n_fft & 1) || a->frames < 2 || a->hop <= 0 || a->hop > a->n_fft) return pg_fail(PG_ERR_SHAPE, "ola_nt: bad sizes");
+    if (a->n < 0 || a->n > 64) return pg_fail(PG_ERR_SHAPE, "ola_nt: 1..64 clips per call");
     if (a->workspace_bytes < 256) return pg_fail(PG_ERR_WORKSPACE, "ola_nt: workspace too small");
+    const unsigned n = a->n ? (unsigned)a->n : 1u;          // n = 0: one clip (the v0.2 layout of the struct)
     hipStream_t st = (hipStream_t)stream;
     unsigned* peak = (unsigned*)a->workspace;
     hipError_t e = hipMemsetAsync(peak, 0, 256, st);
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     const int len = a->hop * (a->frames - 1);
     int bx = (len + 255) / 256; if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(ola_nt_kernel, dim3(bx), dim3(256), 0, st, *a, peak);
-    if (a->normalize) hipLaunchKernelGGL(istft_normalize_kernel, dim3(bx, 1), dim3(256), 0, st, a->audio, len, (const unsigned*)peak);
+    hipLaunchKernelGGL(ola_nt_kernel, dim3(bx, n), dim3(256), 0, st, *a, peak);
+    if (a->normalize) hipLaunchKernelGGL(istft_normalize_kernel, dim3(bx, n), dim3(256), 0, st, a->audio, len, (const unsigned*)peak);
     e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
 }

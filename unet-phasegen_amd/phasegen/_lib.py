@@ -102,12 +102,13 @@ class IstftArgs(C.Structure):
 
 class GlArgs(C.Structure):
     _fields_ = [("bins", C.c_int32), ("frames", C.c_int32), ("S", C.c_void_p), ("mag", C.c_void_p), ("x", C.c_void_p),
-                ("spec_out", C.c_void_p)]
+                ("spec_out", C.c_void_p), ("n", C.c_int32), ("_pad0", C.c_int32)]
 
 
 class OlaArgs(C.Structure):
     _fields_ = [("n_fft", C.c_int32), ("frames", C.c_int32), ("hop", C.c_int32), ("normalize", C.c_int32),
-                ("fr", C.c_void_p), ("audio", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("fr", C.c_void_p), ("audio", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("n", C.c_int32), ("_pad0", C.c_int32)]
 
 
 # every symbol include/phasegen.h declares: name -> (restype, argtypes)

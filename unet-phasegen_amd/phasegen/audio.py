@@ -68,44 +68,66 @@ def _synthesis_matrix(bins, device):
     return _synth[key]
 
 
-def griffin_lim(spec, n_fft, hop_length, n_iter, init=None, seed=None):
-    """utils.py:85-134 on device.  ``spec``: magnitudes (n_fft/2, frames) (DC already dropped).  Each iteration:
-    STFT (pg_stft) -> keep phase, impose magnitude (pg_gl_project) -> inverse transform as a 1x1 convolution on the
-    fp32-MFMA conv kernel with the synthesis matrix above -> overlap-add (pg_ola_nt).  The start vector replaces
-    ``np.random.randn`` (utils.py:116): pass ``init`` or a ``seed`` for a reproducible one.
-    Returns (audio float32 numpy peak-normalised, new_spec complex numpy, loss float) like the reference."""
+def griffin_lim_batch(mag, n_fft, hop_length, n_iter, init=None, seed=None):
+    """utils.py:85-134 for a BATCH of clips, device tensors in and out: ``mag`` (n, n_fft/2, frames) magnitudes (DC dropped).
+    Every iteration is four launches whatever n is -- STFT (pg_stft) -> keep phase, impose magnitude (pg_gl_project) -> the
+    2046-point inverse transform as ONE 1x1 convolution on the fp32-MFMA conv kernel (batch axis = clips) -> overlap-add
+    (pg_ola_nt) -- and clip c's result is bit-identical to running it alone (no kernel reduces across clips).
+    ``init``: (n, hop * (frames - 1)) start signals; else clip c starts from N(0, 1) drawn with seed ``seed + c`` (replaces
+    ``np.random.randn``, utils.py:116).  Returns device tensors (audio (n, length) peak-normalised per clip, new_spec
+    (n, 2, bins, frames) = [re; im] of the last projection, loss (n,))."""
     dev = _dev()
-    mag = torch.from_numpy(np.ascontiguousarray(np.abs(spec) if np.iscomplexobj(spec) else spec, dtype=np.float32)).to(dev)
-    bins, frames = mag.shape
+    if not (torch.is_tensor(mag) and mag.is_cuda and mag.dtype == torch.float32 and mag.dim() == 3):
+        raise ValueError("griffin_lim_batch: mag must be a float32 device tensor (n, bins, frames)")
+    mag = mag.contiguous()
+    n, bins, frames = mag.shape
     if bins != n_fft // 2:
         raise ValueError(f"griffin_lim: spec has {bins} rows, expected n_fft/2 = {n_fft // 2}")
     length = hop_length * (frames - 1)
     if init is None:
-        g = torch.Generator(device="cpu")
-        g.manual_seed(torch.initial_seed() if seed is None else seed)
-        init = torch.randn(length, generator=g, dtype=torch.float64).numpy()
-    recon = torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32)).to(dev)
+        base = torch.initial_seed() if seed is None else seed
+        rows = []
+        for c in range(n):
+            g = torch.Generator(device="cpu")
+            g.manual_seed(base + c)
+            rows.append(torch.randn(length, generator=g, dtype=torch.float64))
+        init = torch.stack(rows).to(torch.float32)
+    audio = torch.empty(n, length, device=dev)
+    new_spec = torch.empty(n, 2, bins, frames, device=dev)
+    loss = torch.full((n,), float("nan"), device=dev)
     W = _synthesis_matrix(bins, dev)
     N = 2 * (bins - 1)
-    x = torch.zeros(1, N, frames, device=dev)
-    fr = torch.empty(1, N, frames, device=dev)
-    S = torch.empty(1, 2, bins, frames, device=dev)
-    new_spec = torch.empty(2, bins, frames, device=dev)
-    prev = torch.empty_like(recon)
-    loss = float("nan")
-    for _ in range(n_iter):
-        ops.stft(recon[None], n_fft, hop_length, out=S)
-        ops.gl_project(S[0], mag, x[0], new_spec)
-        ops.conv_fwd(x, W, fr, 1, 0, precision="fp32", schedule=0)   # the inverse DFT is always exact-fp32 MFMA
-        prev.copy_(recon)
-        ops.ola_nt(fr[0], hop_length, recon)
-    if n_iter > 0:
-        loss = float(torch.sqrt(torch.sum((recon - prev) ** 2) / recon.numel()))
-    audio = recon.cpu().numpy()
+    for c0 in range(0, n, 64):                                   # pg_ola_nt keeps one peak word per clip in 256 bytes
+        c1 = min(n, c0 + 64)
+        m = c1 - c0
+        recon = torch.as_tensor(init[c0:c1]).to(dev, torch.float32).contiguous()
+        x = torch.zeros(m, N, frames, device=dev)
+        fr = torch.empty(m, N, frames, device=dev)
+        S = torch.empty(m, 2, bins, frames, device=dev)
+        prev = torch.empty_like(recon)
+        for _ in range(n_iter):
+            ops.stft(recon, n_fft, hop_length, out=S)
+            ops.gl_project(S, mag[c0:c1], x, new_spec[c0:c1])
+            ops.conv_fwd(x, W, fr, 1, 0, precision="fp32", schedule=0)   # the inverse DFT is always exact-fp32 MFMA
+            prev.copy_(recon)
+            ops.ola_nt(fr, hop_length, recon)
+        if n_iter > 0:
+            loss[c0:c1] = torch.sqrt(torch.sum((recon - prev) ** 2, dim=1) / length)
+        peak = recon.abs().amax(dim=1, keepdim=True)
+        audio[c0:c1] = torch.where(peak > torch.finfo(torch.float32).tiny, recon / peak, recon)
+    return audio, new_spec, loss
+
+
+def griffin_lim(spec, n_fft, hop_length, n_iter, init=None, seed=None):
+    """utils.py:85-134 with the reference's signature: ``spec`` magnitudes (n_fft/2, frames) (numpy, DC already dropped).
+    One clip of ``griffin_lim_batch``.  Returns (audio float32 numpy peak-normalised, new_spec complex numpy, loss float)."""
+    dev = _dev()
+    mag = torch.from_numpy(np.ascontiguousarray(np.abs(spec) if np.iscomplexobj(spec) else spec, dtype=np.float32)).to(dev)
+    if init is not None:
+        init = torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32))[None]
+    a, ns, loss = griffin_lim_batch(mag[None], n_fft, hop_length, n_iter, init=init, seed=seed)
+    audio = a[0].cpu().numpy()
     if not np.all(np.isfinite(audio)):
         raise ValueError("Audio buffer is not finite everywhere")
-    peak = np.max(np.abs(audio))
-    if peak > np.finfo(np.float32).tiny:
-        audio = audio / peak
-    ns = new_spec.cpu().numpy()
-    return audio, (ns[0] + 1j * ns[1]).astype(np.complex64), loss
+    ns = ns[0].cpu().numpy()
+    return audio, (ns[0] + 1j * ns[1]).astype(np.complex64), float(loss[0])

@@ -336,14 +336,22 @@ def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False, precisi
 
 
 # ---- bf16-resident forward path (BASELINE configs[4]; csrc/conv_h.hip) -----------------------------------------------------
+H_HEAD = 32      # PG_H_HEAD: zero elements the bf16-resident kernels may read in front of a tensor's first row
+H_TAIL = 40      # zero tail of every row that covers each layer of the U-Net (pg_conv_fwd_h_supported checks a layer's need)
+
+
 def h_pitch(L):
-    """Row pitch (elements) of a bf16 activation tensor with L frames: even, 16-byte rows, at least one zero tail element."""
-    return (L + 1 + 7) // 8 * 8
+    """Row pitch (elements) of a bf16 activation tensor with L frames: 16-byte rows and a zero tail of at least H_TAIL elements
+    (the kernels gather row windows as unchecked 16-byte pieces: the convolution's zero padding is read from the tails)."""
+    return (L + H_TAIL + 7) // 8 * 8
 
 
 def h_alloc(B, Cc, L, device):
-    """Zero-filled bf16 (B, C, pitch) tensor: producers only ever write frames [0, L), so the zero tails stay zero."""
-    return torch.zeros(B, Cc, h_pitch(L), device=device, dtype=torch.bfloat16)
+    """Zero-filled bf16 (B, C, pitch) tensor with H_HEAD zero elements in front of it (a view into a slightly larger buffer):
+    producers only ever write frames [0, L), so the zero tails -- and the head -- stay zero."""
+    pitch = h_pitch(L)
+    flat = torch.zeros(H_HEAD + B * Cc * pitch, device=device, dtype=torch.bfloat16)
+    return flat[H_HEAD:].view(B, Cc, pitch)
 
 
 def _h3(t, L, name):
@@ -607,11 +615,19 @@ def istft(a_t, b_t, hop, mode=0, normalize=True, single_frame=None):
 
 
 def gl_project(S, mag, x, spec_out=None):
-    """utils.py:122-124: new_spec = mag * exp(1j * angle(S)) -> GEMM operand x (2*bins-2, frames) (+ [re; im] copy)."""
+    """utils.py:122-124: new_spec = mag * exp(1j * angle(S)) -> GEMM operand x (2*bins-2, frames) (+ [re; im] copy).
+    Batched: S (n, 2, bins, frames), mag (n, bins, frames), x (n, 2*bins-2, frames), spec_out (n, 2, bins, frames)."""
     a = _lib.GlArgs()
-    a.bins, a.frames = mag.shape
+    if mag.dim() == 3:
+        a.n, a.bins, a.frames = mag.shape
+        if tuple(S.shape) != (a.n, 2, a.bins, a.frames) or tuple(x.shape) != (a.n, 2 * a.bins - 2, a.frames):
+            raise ValueError("gl_project: batched shapes inconsistent")
+    else:
+        a.bins, a.frames = mag.shape
     a.S, a.mag, a.x = _dense(S, "S"), _dense(mag, "mag"), _dense(x, "x")
     if spec_out is not None:
+        if spec_out.shape != S.shape:
+            raise ValueError("gl_project: spec_out must have S's shape")
         a.spec_out = _dense(spec_out, "spec_out")
     _lib.check(_lib.load().pg_gl_project(C.byref(a), _stream()), "gl_project")
 
@@ -621,9 +637,15 @@ _caches.append(_ola_ws)
 
 
 def ola_nt(frames_nt, hop, audio, normalize=False):
-    """Overlap-add of (n_fft, frames)-major windowed frames (any even n_fft) into ``audio`` (hop * (frames - 1),)."""
+    """Overlap-add of (n_fft, frames)-major windowed frames (any even n_fft) into ``audio`` (hop * (frames - 1),); batched:
+    frames (n, n_fft, frames) -> audio (n, hop * (frames - 1)), n <= 64, each clip normalised by its own peak."""
     a = _lib.OlaArgs()
-    a.n_fft, a.frames = frames_nt.shape
+    if frames_nt.dim() == 3:
+        a.n, a.n_fft, a.frames = frames_nt.shape
+        if tuple(audio.shape) != (a.n, hop * (a.frames - 1)):
+            raise ValueError("ola_nt: audio must be (n, hop * (frames - 1))")
+    else:
+        a.n_fft, a.frames = frames_nt.shape
     a.hop, a.normalize = hop, int(normalize)
     a.fr, a.audio = _dense(frames_nt, "frames"), _dense(audio, "audio")
     ws = _ola_ws.get(audio.device, lambda: 256)

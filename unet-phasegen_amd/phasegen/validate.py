@@ -13,22 +13,20 @@ from . import audio
 
 @torch.no_grad()
 def validation_metrics(model, val_batch, hop_length=512, n_fft=2048, gl_iters=250, gl_seed=0):
-    """val_batch: (n, 2, bins, frames) = [logmag; angle] on the device.  Returns {"MSE", "NOPMSE", "LMSE"} floats."""
+    """val_batch: (n, 2, bins, frames) = [logmag; angle] on the device.  Returns {"MSE", "NOPMSE", "LMSE"} floats.
+    Nothing leaves the device before the three means: the forwards are batch-of-one (train-mode BatchNorm, train.py:76: the
+    statistics of a clip must not see the others), everything else -- the three ISTFTs and the Griffin-Lim comparator -- is
+    batched over the clips."""
     val_batch = val_batch.contiguous()
     n, _, bins, _ = val_batch.shape
-    mses, nops, lims = [], [], []
+    logmag, ang = val_batch[:, 0].contiguous(), val_batch[:, 1].contiguous()
+    phase = torch.empty_like(logmag)
     for c in range(n):
-        vd = val_batch[c:c + 1]
-        pred = model.forward(vd[:, 0])                                   # batch of one, train-mode BN (train.py:76)
-        logmag, ang = vd[:, 0], vd[:, 1]
-        orig = audio.synthesize(logmag, ang.contiguous(), hop_length)[0]
-        hyb = audio.synthesize(logmag, pred[:, :bins].contiguous(), hop_length)[0]
-        nop = audio.synthesize(logmag, torch.zeros_like(logmag), hop_length)[0]
-        mag = (torch.exp(logmag[0]) - 1.0).cpu().numpy()
-        lim, _, _ = audio.griffin_lim(mag, n_fft, hop_length, gl_iters, seed=gl_seed + c)
-        lim = torch.from_numpy(lim).to(orig.device)
-        mses.append(torch.abs(orig - hyb).mean())
-        nops.append(torch.abs(orig - nop).mean())
-        lims.append(torch.abs(orig - lim).mean())
-    f = lambda v: float(torch.stack(v).mean())      # noqa: E731  (clips have equal length: mean of means == global mean)
-    return {"MSE": f(mses), "NOPMSE": f(nops), "LMSE": f(lims)}
+        phase[c] = model.forward(val_batch[c:c + 1, 0])[0, :bins]       # batch of one, train-mode BN (train.py:76)
+    orig = audio.synthesize(logmag, ang, hop_length)
+    hyb = audio.synthesize(logmag, phase, hop_length)
+    nop = audio.synthesize(logmag, torch.zeros_like(logmag), hop_length)
+    lim, _, _ = audio.griffin_lim_batch(torch.exp(logmag) - 1.0, n_fft, hop_length, gl_iters, seed=gl_seed)
+    # (clips have equal length: the mean over everything == the reference's mean of per-clip means)
+    res = torch.stack([torch.abs(orig - hyb).mean(), torch.abs(orig - nop).mean(), torch.abs(orig - lim).mean()]).cpu()
+    return {"MSE": float(res[0]), "NOPMSE": float(res[1]), "LMSE": float(res[2])}
