@@ -123,6 +123,7 @@ typedef struct pg_convh_args {
 } pg_convh_args;
 int pg_conv_fwd_h(const pg_convh_args* a, void* stream);
 int pg_conv_fwd_h_supported(const pg_convh_args* a);   /* 1 / 0: geometry (sizes, strides, pitches; pointers ignored) is covered */
+int pg_conv_fwd_h_describe(const pg_convh_args* a, char* buf, int32_t buflen);   /* launch plan without launching, as pg_conv_describe */
 /* bf16 shadow of one conv layer's weights: Conv1d (Cout, Cin, k) -> [o][(q, j)] (a cast); ConvTranspose1d (Cin, Cout, k) ->
  * [(o, phase)][(q, tap)] with the taps of a phase in the order the gather-form kernel reads them, ceil(k / stride) taps per
  * phase rounded up to a power of two with zero weights (k = 5, stride 2: 4).  wh holds pg_shadow_elems(...) elements. */

@@ -33,8 +33,14 @@ GEOMS = [
 ]
 
 
+# schedule word: bits 0-1 work split (0 auto, 1 one tile per workgroup, 2 stream-K), bits 5-6 tile family (32: 128 x 256 on 4 waves,
+# 64: 128 x 512 and 96: 256 x 256 on 8 waves; 0: automatic)
+SCHEDS = [0, 1, 2, 32 | 1, 32 | 2, 64 | 1, 64 | 2, 96 | 1, 96 | 2]
+
+
 @pytest.mark.parametrize("geom", GEOMS)
-@pytest.mark.parametrize("sched", [0, 1, 2], ids=["auto", "tile-per-wg", "stream-k"])
+@pytest.mark.parametrize("sched", SCHEDS, ids=["auto", "tile-per-wg", "stream-k", "128x256/tile", "128x256/stream-k", "128x512/tile",
+                                               "128x512/stream-k", "256x256/tile", "256x256/stream-k"])
 def test_conv_fwd_h_vs_float64_of_the_bf16_operands(geom, sched):
     from phasegen import ops
     tr, Cin, Cout, k, s, p, Lin, B = geom

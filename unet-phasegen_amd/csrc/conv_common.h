@@ -520,6 +520,10 @@ hipError_t launch_im2col(int kind, const IgemmParams& p, int grid, hipStream_t s
 hipError_t launch_raw_ft(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw.hip (F / T, tile 128 x 256)
 hipError_t launch_raw_ft_tall(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw_tall.hip (256 x 128)
 hipError_t launch_raw_g(const IgemmParams& p, int grid, hipStream_t st, int prec);              // conv_raw_wgrad.hip
-hipError_t launch_h(int kind, const IgemmParams& p, int grid, hipStream_t st);                  // conv_h.hip (bf16-resident forward)
-bool h_supported(int kind, const IgemmParams& p);
+hipError_t launch_h(int kind, const IgemmParams& p, int grid, hipStream_t st);                  // conv_h.hip (bf16-resident forward, 128 x 256, 4 waves)
+// conv_h2.hip: the same on 8 waves, one workgroup per CU; wm = 1: tile 128 x 512, wm = 2: tile 256 x 256
+hipError_t launch_h2(int kind, int wm, const IgemmParams& p, int grid, hipStream_t st);
+hipError_t launch_h2_fixup(int kind, int wm, const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
+bool h_supported_tn(int kind, const IgemmParams& p, int tn);      // geometry covered by a bf16-resident kernel whose tile is tn columns wide
+inline bool h_supported(int kind, const IgemmParams& p) { return h_supported_tn(kind, p, 256); }
 }  // namespace pgconv

@@ -23,12 +23,12 @@
 // K must be whole channels per slab (Q % (32 / min(taps, 32)) == 0); otherwise the caller uses the fp32-tensor path.
 // Work decomposition, stream-K split, fixup kernels and epilogues are the shared ones (conv_common.h).
 #include "conv_common.h"
+#include "conv_h_frag.h"
 
 namespace {
 
 constexpr int KB = 32;                    // k per slab (two MFMA k-steps of 16)
 constexpr int H_HEAD = 32;                // zero elements the caller guarantees in front of x (bytes: 64)
-typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 // window geometry shared by the kernel and the host-side check: dwords reserved per channel window
 __host__ __device__ constexpr int h_rsd(int sc) { return sc == 1 ? 256 : 384; }
@@ -137,45 +137,6 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
         }                                                                                                    \
     }
 
-#define H_MMA(STAGE_PTR)                                                                                     \
-            {                                                                                                \
-                const float* As = (STAGE_PTR);                                                               \
-                typedef const __attribute__((address_space(3))) unsigned* lds_u32;                           \
-                const lds_u32 Bd = (lds_u32)((STAGE_PTR) + TA);                                              \
-                const int sw = (r >> 2) & 3;                                                                 \
-                const float* ap = As + r * 16;                                                               \
-                _Pragma("unroll") for (int s = 0; s < 2; ++s) {      /* MFMA k-steps: k = 16 s + 8 h + (0 .. 7) */ \
-                    s16x8 a[MBW], b[NBW];                                                                    \
-                    _Pragma("unroll") for (int i = 0; i < MBW; ++i)                                          \
-                        a[i] = __builtin_bit_cast(s16x8, *reinterpret_cast<const f32x4*>(ap + i * 32 * 16 + (((2 * s + h) ^ sw) << 2))); \
-                    _Pragma("unroll") for (int jb = 0; jb < NBW; ++jb) {                                     \
-                        unsigned o[4];                                                                       \
-                        if (TJ >= 8) {                                                                       \
-                            /* channel / first tap of this lane's 8 k:  TJ 32: (0, 16 s + 8 h)  16: (s, 8 h)  8: (2 s + h, 0) */ \
-                            const int qi = TJ == 32 ? 0 : (TJ == 16 ? s : 2 * s + h);                        \
-                            const int tap0 = TJ == 32 ? 16 * s + 8 * h : (TJ == 16 ? 8 * h : 0);             \
-                            const lds_u32 bp = Bd + qi * RSD + bdw[jb] + (tap0 >> 1);                        \
-                            unsigned d[5];                                                                   \
-                            _Pragma("unroll") for (int i = 0; i < 5; ++i) d[i] = bp[i];                      \
-                            _Pragma("unroll") for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], bsh[jb]); \
-                        } else {                                         /* TJ == 4: two channels x 4 taps */ \
-                            _Pragma("unroll") for (int cc = 0; cc < 2; ++cc) {                               \
-                                const lds_u32 bp = Bd + (4 * s + 2 * h + cc) * RSD + bdw[jb];                \
-                                unsigned d[3];                                                               \
-                                _Pragma("unroll") for (int i = 0; i < 3; ++i) d[i] = bp[i];                  \
-                                _Pragma("unroll") for (int i = 0; i < 2; ++i) o[2 * cc + i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], bsh[jb]); \
-                            }                                                                                \
-                        }                                                                                    \
-                        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));                         \
-                        const u32x4v ov = {o[0], o[1], o[2], o[3]};                                          \
-                        b[jb] = __builtin_bit_cast(s16x8, ov);                                               \
-                    }                                                                                        \
-                    _Pragma("unroll") for (int i = 0; i < MBW; ++i)                                          \
-                        _Pragma("unroll") for (int jb = 0; jb < NBW; ++jb)                                   \
-                            acc.c[i][jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[jb]), acc.c[i][jb], 0, 0, 0); \
-                }                                                                                            \
-            }
-
 #pragma unroll
         for (int hf = 0; hf < SPB; ++hf) H_ISSUE(lds + hf * STG, sb + hf)
         __syncthreads();
@@ -184,12 +145,10 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
 #pragma unroll
             for (int hf = 0; hf < SPB; ++hf) H_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, sl + SPB + hf)
             __builtin_amdgcn_sched_barrier(0);
-            H_MMA(lds + cur * SSTG)
-            if (SPB == 2 && sl + 1 < se) H_MMA(lds + cur * SSTG + STG)
+            h_mma_group<TJ, RSD, TA, STG>(lds + cur * SSTG, min(SPB, se - sl), r, h, wm, bdw, bsh, acc);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
-#undef H_MMA
 #undef H_ISSUE
         if (sb == 0 && se == p.nslab) {
             if (TKIND) epilogue_t<S, MBW, NBW>(p, acc, m0, n0, lane, wm, wn);
@@ -208,40 +167,7 @@ hipError_t launch1(const IgemmParams& p, int grid, hipStream_t st) {
 
 }  // namespace
 
-// Host-side mirror of the kernel's window geometry: do the windows of every possible tile fit the reserved dwords, and is the
-// zero tail of the caller's rows long enough for the unchecked 16-byte window pieces (contract at the top of this file)?
-bool pgconv::h_supported(int kind, const IgemmParams& p) {
-    const bool t = kind == KIND_T;
-    if (kind == KIND_G) return false;
-    if (t) { if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 5 && p.s == 2))) return false; }
-    else if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
-    const int kwp = t ? pg_shadow_taps(p.k, p.s) : p.k, tj = kwp < 32 ? kwp : 32, nq = 32 / tj, sc = t ? 1 : p.s;
-    if (p.Q % nq || (p.x_pitch & 1) || (p.x_bs & 1) || p.x_pitch <= p.Lx) return false;
-    const int lcol = t ? p.U : p.Ly, rsd = h_rsd(sc);
-    const int pos_mid = t ? p.u_off - (tj - 1) : -p.p, shm = pos_mid & 1;
-    const int ndm = h_round4((sc * (lcol - 1) + tj + shm + 1) >> 1);
-    // elements of a row's neighbourhood a window piece can touch: [pos_mid - shm, pos_mid - shm + 2 ndm) for a sample's first
-    // column at frame 0; a first segment that starts at column t0 ends no later (its window is the same one cut at t0, rounded
-    // up to a piece: + 6 elements at most)
-    const int left = pos_mid - shm < 0 ? -(pos_mid - shm) : 0;
-    const int right = pos_mid - shm + 2 * ndm + 6 - p.Lx;
-    const int tail = p.x_pitch - p.Lx;
-    if (left > H_HEAD || tail < left || tail < right) return false;
-    // the kernel lays the samples' windows out back to back (segment 0, full middle segments, last partial one): the worst
-    // first-column position t0 must fit the reserved dwords
-    int need = 0;
-    for (int t0 = 0; t0 < lcol; ++t0) {
-        const int nc0 = lcol - t0 < RBN ? lcol - t0 : RBN, rem = RBN - nc0;
-        const int sh0 = (pos_mid + sc * t0) & 1;
-        int nmid = rem / lcol, nlast = rem - nmid * lcol;                        // full middle samples, columns of the last one
-        if (1 + nmid + (nlast ? 1 : 0) > p.B) { nlast = 0; if (1 + nmid > p.B) nmid = p.B - 1; }   // only B samples exist
-        // (the last, partial segment is READ up to its last column's taps only, but its pieces are issued like a full one's:
-        //  what must fit is the dwords that are read)
-        const int n = h_round4((sc * (nc0 - 1) + tj + sh0 + 1) >> 1) + nmid * ndm + (nlast ? (sc * (nlast - 1) + tj + shm + 2) >> 1 : 0);
-        if (n > need) need = n;
-    }
-    return need <= rsd;
-}
+// (the host-side mirror of the window geometry -- pgconv::h_supported_tn -- lives in conv_h2.hip, shared by both tile families)
 
 hipError_t pgconv::launch_h(int kind, const IgemmParams& p, int grid, hipStream_t st) {
     if (kind == KIND_F) {

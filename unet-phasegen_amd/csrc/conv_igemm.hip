@@ -92,16 +92,18 @@ struct Knobs {
     int no_tall;      // 1 = never use the tall 256 x 128 raw tile
     int oversub;      // stream-K grid = up to oversub x resident workgroup slots
     int contended;    // other kernels (RCCL collectives) are expected to hold part of the chip: always take the finer split
+    int hvar;         // pg_conv_fwd_h only: tile family, 0 automatic, 1 = 128 x 256 (4 waves), 2 = 128 x 512, 3 = 256 x 256 (8 waves)
     char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
 };
 int decode_knobs(const pg_conv_args* a, Knobs& k) {
     if (a->precision < 0 || a->precision > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv: precision must be PG_PREC_FP32, PG_PREC_BF16 or PG_PREC_BF16X3");
     const int sc = a->schedule;
-    if (sc < 0 || (sc & ~0xf1f) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
+    if (sc < 0 || (sc & ~0xf7f) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
     k.prec = a->precision;
     k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
     k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
     k.contended = (sc >> 4) & 1;
+    k.hvar = (sc >> 5) & 3;
     k.desc = nullptr; k.desc_len = 0;
     return PG_OK;
 }
@@ -115,9 +117,10 @@ int cu_count() { return pg_cu_count(); }
 // degrades gracefully when slots are taken (16 of 512 slots held: 1x split 33 -> 58 ms, one-tile-per-workgroup 32 -> 43 ms,
 // 4x split 33 -> 37 ms).  Small problems (less than 8 slabs per resident slot, or no workspace) run one tile per
 // workgroup.  mode: 0 auto, 1 force one tile per workgroup, 2 force stream-K (tests).
-int pick_grid(long tiles, int nslab, IgemmParams& p, long ws_bytes, int mode, int oversub, int contended) {
+int pick_grid(long tiles, int nslab, IgemmParams& p, long ws_bytes, int mode, int oversub, int contended, int wg_per_cu = WG_PER_CU,
+              long ws_per_wg = WS_PER_WG) {
     const long total = tiles * (long)nslab;
-    const long slots = (long)cu_count() * WG_PER_CU;
+    const long slots = (long)cu_count() * wg_per_cu;
     p.whole = 0;
     // A tile count that is a whole multiple of the resident slots quantises perfectly: whole tiles per workgroup, no partial
     // tiles through the workspace and no fixup launch (measured: the fixups of the five such layers of the U-Net cost 0.5 ms
@@ -133,7 +136,7 @@ int pick_grid(long tiles, int nslab, IgemmParams& p, long ws_bytes, int mode, in
     long G = slots * mult;
     if (G > MAX_STREAMK_WG) G = (MAX_STREAMK_WG / slots) * slots;
     if (G > total) G = total;
-    const bool can = p.ws && ws_bytes >= G * WS_PER_WG && total < 0x7fffffffL;
+    const bool can = p.ws && ws_bytes >= G * ws_per_wg && total < 0x7fffffffL;
     if (mode == 1 || !can) return (int)tiles;
     if (mode == 2) return (int)G;
     // Hybrid: a tile count slightly above a multiple of the slots (1056, 528) runs its full waves as whole tiles and splits only
@@ -141,7 +144,7 @@ int pick_grid(long tiles, int nslab, IgemmParams& p, long ws_bytes, int mode, in
     // fixup then touches 32 tiles instead of 1056.  Not when the chip is shared (see above).
     if (!contended && tiles > slots) {
         const long whole = tiles / slots * slots, rem = tiles - whole;
-        if (rem * nslab >= slots * 8 && whole + slots <= MAX_STREAMK_WG && ws_bytes >= (whole + slots) * WS_PER_WG) {
+        if (rem * nslab >= slots * 8 && whole + slots <= MAX_STREAMK_WG && ws_bytes >= (whole + slots) * ws_per_wg) {
             p.whole = (int)whole;
             return (int)(whole + slots);
         }
@@ -412,7 +415,15 @@ extern "C" int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, in
 }
 
 // ---- bf16-resident forward (conv_h.hip) ----------------------------------------------------------------------------------
-static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query) {
+// automatic tile family of pg_conv_fwd_h (measured on MI355X at the U-Net's layer shapes, tools/convh_bench.py)
+static int h_auto_variant(int kwp, int sc, long rows, long cols) {
+    (void)rows; (void)cols;
+    // >= 8 taps per channel at unit window step, or 32: the wide 8-wave tile (D0, D1, U1, U0: +4 ... 7 %); short taps / stride-2
+    // windows (D2, D3, U2, U3), whose window bytes double with the tile width: the 4-wave 128 x 256 tile
+    return (kwp >= 32 || (kwp >= 8 && sc == 1)) ? 2 : 1;
+}
+
+static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, char* desc = nullptr, int desc_len = 0) {
     if (!a) return pg_fail(PG_ERR_NULL, "conv_fwd_h: null args");
     if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->Lin <= 0 || a->Lout <= 0 || a->k <= 0 || a->stride <= 0 || a->pad < 0)
         return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: non-positive dimension");
@@ -448,24 +459,40 @@ static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query) {
         p.U = (p.Ly - 1 + p.p) / p.s - p.u_off + 1;
         if (p.U <= 0) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: empty output");
     }
-    if (!pgconv::h_supported(kind, p)) return pg_fail(PG_ERR_UNSUPPORTED, "conv_fwd_h: geometry not covered by the bf16-resident kernels (use the fp32-tensor entry points)");
+    // Tile family (conv_h2.hip's header has the bytes-per-FLOP arithmetic): 1 = 128 x 256 on 4 waves, two workgroups per CU;
+    // 2 = 128 x 512 and 3 = 256 x 256 on 8 waves, one workgroup per CU.  schedule bits 5-6 force one (tests, tools/convh_bench.py).
+    const bool ok1 = pgconv::h_supported_tn(kind, p, 256), ok2 = pgconv::h_supported_tn(kind, p, 512);
+    if (!ok1) return pg_fail(PG_ERR_UNSUPPORTED, "conv_fwd_h: geometry not covered by the bf16-resident kernels (use the fp32-tensor entry points)");
     if (query) return PG_OK;
     const long rows = tr ? (long)p.M * p.s : p.M, cols = (long)p.B * (tr ? p.U : p.Ly), Ktot = (long)p.Q * kwp;
-    p.tilesM = (int)((rows + RBM - 1) / RBM);
-    p.tilesN = (int)((cols + RBN - 1) / RBN);
-    p.tn_stride = RBN;
+    int var = kn.hvar ? kn.hvar : h_auto_variant(kwp, tr ? 1 : p.s, rows, cols);
+    if (var == 2 && !ok2) var = 3;
+    const int wm = var == 3 ? 2 : 1, tm = var == 3 ? 2 * RBM : RBM, tn = var == 2 ? 2 * RBN : RBN;
+    p.tilesM = (int)((rows + tm - 1) / tm);
+    p.tilesN = (int)((cols + tn - 1) / tn);
+    p.tn_stride = tn;
     p.nslab = (int)(Ktot / 32);
     p.ws = (float*)a->workspace;
     const long tiles = (long)p.tilesM * p.tilesN;
     if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: empty or oversize grid");
-    const int grid = pick_grid(tiles, p.nslab, p, a->workspace_bytes, kn.force_mode, kn.oversub, kn.contended);
+    const int grid = var == 1 ? pick_grid(tiles, p.nslab, p, a->workspace_bytes, kn.force_mode, kn.oversub, kn.contended)
+                              : pick_grid(tiles, p.nslab, p, a->workspace_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG);
     const bool split = grid != tiles && !(tiles % grid == 0);
+    if (desc) {
+        snprintf(desc, (size_t)desc_len, "conv_h%s_kernel<%d, %d, %s%s>|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", var == 1 ? "" : "2",
+                 (tr && p.k == 5) ? 8 : p.k, p.s, tr ? "true" : "false", var == 1 ? "" : (var == 2 ? ", 1" : ", 2"), grid, tiles, p.nslab, (int)split, p.whole);
+        return PG_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = pgconv::launch_h(kind, p, grid, st);
+    hipError_t e = var == 1 ? pgconv::launch_h(kind, p, grid, st) : pgconv::launch_h2(kind, wm, p, grid, st);
     if (e == hipSuccess && split) {
-        if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 4, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
-        else hipLaunchKernelGGL((conv_fixup_kernel<1, 4, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
-        e = hipGetLastError();
+        const unsigned blocks = (unsigned)((tiles - p.whole) * 8);
+        if (var != 1) e = pgconv::launch_h2_fixup(kind, wm, p, grid, blocks, st);
+        else {
+            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 4, 2, 4>), dim3(blocks), dim3(NT), 0, st, p, grid);
+            else hipLaunchKernelGGL((conv_fixup_kernel<1, 4, 2, 4>), dim3(blocks), dim3(NT), 0, st, p, grid);
+            e = hipGetLastError();
+        }
     }
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     return PG_OK;
@@ -474,6 +501,12 @@ static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query) {
 extern "C" int pg_conv_fwd_h(const pg_convh_args* a, void* stream) { return conv_fwd_h_impl(a, stream, false); }
 // 1 if pg_conv_fwd_h covers this geometry (sizes, strides and pitches of `a`; pointers may be NULL), else 0: pure host check
 extern "C" int pg_conv_fwd_h_supported(const pg_convh_args* a) { return conv_fwd_h_impl(a, nullptr, true) == PG_OK ? 1 : 0; }
+// launch plan of a pg_conv_fwd_h call without launching it (as pg_conv_describe; pointers must be non-NULL, they are not read)
+extern "C" int pg_conv_fwd_h_describe(const pg_convh_args* a, char* buf, int32_t buflen) {
+    if (!buf || buflen < 128) return pg_fail(PG_ERR_NULL, "conv_fwd_h_describe: buf of >= 128 bytes required");
+    buf[0] = 0;
+    return conv_fwd_h_impl(a, nullptr, false, buf, buflen);
+}
 
 // Workspace a caller should hand to the conv entry points (pg_conv_args.workspace) so that badly quantised tile counts
 // can be balanced over all CUs (stream-K).  Without it every call falls back to one-tile-per-workgroup scheduling.

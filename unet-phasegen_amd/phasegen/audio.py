@@ -3,6 +3,7 @@ import numpy as np
 import torch
 
 from . import ops
+from ._lib import SCHED_TILE_PER_WG as _lib_sched_tile_per_wg
 
 
 def _dev():
@@ -108,7 +109,9 @@ def griffin_lim_batch(mag, n_fft, hop_length, n_iter, init=None, seed=None):
         for _ in range(n_iter):
             ops.stft(recon, n_fft, hop_length, out=S)
             ops.gl_project(S, mag[c0:c1], x, new_spec[c0:c1])
-            ops.conv_fwd(x, W, fr, 1, 0, precision="fp32", schedule=0)   # the inverse DFT is always exact-fp32 MFMA
+            # the inverse DFT is always exact-fp32 MFMA, one whole tile per workgroup: every output sums its 2046 terms in the
+            # same order whatever the number of clips (a stream-K split would depend on the tile count, i.e. on n)
+            ops.conv_fwd(x, W, fr, 1, 0, precision="fp32", schedule=_lib_sched_tile_per_wg)
             prev.copy_(recon)
             ops.ola_nt(fr, hop_length, recon)
         if n_iter > 0:

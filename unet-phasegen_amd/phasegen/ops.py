@@ -436,10 +436,16 @@ def conv_fwd_h(xh, Lin, wh, w_shape, stride, pad, transposed=False, y=None, yh=N
     ws = conv_workspace(xh.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     if _timer is not None and _cur_label is not None and _cur_label not in _timer.plans:
-        kk = 8 if (transposed and k == 5 and stride == 2) else k          # k = 5 runs the k = 8 instantiation on a zero-padded shadow
-        _timer.plans[_cur_label] = f"conv_h_kernel<{kk}, {stride}, {'true' if transposed else 'false'}>|bf16-resident"
+        _timer.plans[_cur_label] = conv_fwd_h_describe(a)
     _lib.check(_lib.load().pg_conv_fwd_h(C.byref(a), _stream()), "conv_fwd_h")
     return a.Lout
+
+
+def conv_fwd_h_describe(a):
+    """pg_conv_fwd_h_describe: 'conv_h[2]_kernel<...>|grid=G|tiles=T|slabs=S|split=0/1|whole=W' for a filled ConvhArgs."""
+    buf = C.create_string_buffer(256)
+    _lib.check(_lib.load().pg_conv_fwd_h_describe(C.byref(a), buf, 256), "conv_fwd_h_describe")
+    return buf.value.decode()
 
 
 def bn_fwd(x, y, gamma, beta, save_mean, save_invstd, running_mean=None, running_var=None, eps=1e-5, momentum=0.1,
