@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NT, 2) void conv_h_kernel(const IgemmParams p) {
 #pragma unroll
             for (int hf = 0; hf < SPB; ++hf) H_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, sl + SPB + hf)
             __builtin_amdgcn_sched_barrier(0);
-            h_mma_group<TJ, RSD, TA, STG>(lds + cur * SSTG, min(SPB, se - sl), r, h, wm, bdw, bsh, acc);
+            h_mma_group<TJ, RSD, TA, STG, SPB>(lds + cur * SSTG, min(SPB, se - sl), r, h, wm, bdw, bsh, acc);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }

@@ -7,8 +7,8 @@
 // window set that grows with TN, for TM x TN x 64 FLOP: the weight bytes per FLOP fall with TN, the window bytes with TM.
 //     U0 (16 taps per channel):  128 x 256: 8 + 2 KB   128 x 512: 8 + 4 KB per 2x the FLOP (-40 %)   256 x 256: 16 + 2 KB per 2x (-10 %)
 //     D3 (4 taps, stride 2):     128 x 256: 8 + 12 KB  128 x 512: 8 + 24 KB per 2x (-20 %)          256 x 256: 16 + 12 KB per 2x (-30 %)
-// so long-tap layers take the wide tile and short-tap layers the square one (host: conv_fwd_h_impl).  With one workgroup per
-// CU a stage pair may use most of the 160 KB of LDS: up to four slabs are gathered per barrier.
+// so long-tap layers take the wide tile (host: conv_fwd_h_impl).  With one workgroup per CU the stages may use most of the 160 KB
+// of LDS: a ring of three groups of up to four slabs, gathered two groups ahead behind counted waits (kernel body).
 #include "conv_common.h"
 #include "conv_h_frag.h"
 
@@ -17,7 +17,27 @@ namespace {
 constexpr int KB = 32;                    // k per slab (two MFMA k-steps of 16)
 constexpr int H_HEAD = 32;                // zero elements the caller guarantees in front of x (PG_H_HEAD)
 constexpr int NT2 = 512;                  // threads per workgroup
-constexpr int H2_LDS = 144 * 1024;        // LDS budget of the two stage groups
+constexpr int H2_LDS = 156 * 1024;        // LDS budget of the ring of three stage groups
+#ifndef PG_H2_SPREAD
+#define PG_H2_SPREAD 1
+#endif
+#ifndef PG_H2_RING
+#define PG_H2_RING 3
+#endif
+#ifndef PG_H2_SPBMAX
+#define PG_H2_SPBMAX 4
+#endif
+constexpr int H2_RING = PG_H2_RING;       // stage groups: one being multiplied, one landed / landing, one just issued
+__host__ __device__ constexpr int h2_spb(int stg_floats) {      // slabs per stage group (= per barrier): as many as the ring affords, <= 4
+    for (int n = PG_H2_SPBMAX; n > 1; --n)
+        if (H2_RING * n * stg_floats * 4 <= H2_LDS) return n;
+    return 1;
+}
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4, expcnt [6:4] and lgkmcnt [11:8] at their maxima)
+template <int N> __device__ __forceinline__ void h2_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit count");
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
 
 __host__ __device__ constexpr int h2_rsd(int sc, int tn) { return (sc == 1 ? 256 : 384) * (tn / 256); }
 __host__ __device__ __forceinline__ int h2_round4(int v) { return (v + 3) & ~3; }
@@ -47,10 +67,12 @@ __global__ __launch_bounds__(NT2, 2) void conv_h2_kernel(const IgemmParams p) {
     constexpr int NAI = TM / 16, NAW = NAI / 8;       // weight tile: 16 rows x 64 B per wave instruction; 1 or 2 per wave
     constexpr int TA = TM * 16;                       // dwords of the weight tile
     constexpr int STG = TA + NI * 256;                // (window region rounded up to whole wave instructions)
-    constexpr int SPB = 8 * STG * 4 <= H2_LDS ? 4 : (4 * STG * 4 <= H2_LDS ? 2 : 1);   // slabs per barrier
+    constexpr int SPB = h2_spb(STG);                  // slabs per stage group = per barrier
     constexpr int SSTG = SPB * STG;
+    // LDS-DMA instructions of one FULL stage group that every wave issues at least (waves with a window instruction more over-wait by it)
+    constexpr int NGRP = SPB * (NAW + NI / 8);
     static_assert(KWP == 4 || KWP == 8 || KWP == 16 || KWP == 32, "taps per channel in K order");
-    static_assert(2 * SSTG * 4 <= 160 * 1024, "LDS budget");
+    static_assert(H2_RING * SSTG * 4 <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int MBW = 4, NBW = 2;
@@ -124,18 +146,54 @@ __global__ __launch_bounds__(NT2, 2) void conv_h2_kernel(const IgemmParams p) {
         }                                                                                                    \
     }
 
+        // Ring of three stage groups with the gathers TWO groups ahead: the weights stream from HBM (a layer's shadow is larger than the
+        // Infinity Cache) and every workgroup that shares a weight panel waits for the same fill, so a gather needs ~2.5 us to land --
+        // one group (4 slabs ~ 3 us of MFMAs) was not enough: stamps showed 280 cycles per slab in the closing barrier's vmcnt(0).
+        // The wait is COUNTED (the youngest group stays in flight) and the barrier is the raw s_barrier: __syncthreads() would drain
+        // every pending LDS-DMA (vmcnt(0)).  Order per iteration: [issue group i+2] [fragments + MFMAs of group i] [wait: group i+1
+        // landed for THIS wave] [barrier: ... for every wave; all reads of group i done, its stage is free for group i+3].
+        PG_STAMP_DECL
+        auto wait_landed = [&](int youngest_first_slab) {       // all gathers done except (at most) the youngest group's
+            if (youngest_first_slab + SPB <= p.nslab) h2_wait_vmcnt<NGRP>();     // that group was issued in full
+            else h2_wait_vmcnt<0>();                             // partial or empty youngest group: drain
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
 #pragma unroll
         for (int hf = 0; hf < SPB; ++hf) H2_ISSUE(lds + hf * STG, sb + hf)
-        __syncthreads();
-        for (int sl = sb; sl < se; sl += SPB) {
-            const int cur = ((sl - sb) / SPB) & 1;
 #pragma unroll
-            for (int hf = 0; hf < SPB; ++hf) H2_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, sl + SPB + hf)
+        for (int hf = 0; hf < SPB; ++hf) H2_ISSUE(lds + SSTG + hf * STG, sb + SPB + hf)
+        __builtin_amdgcn_sched_barrier(0);
+        wait_landed(sb + SPB);
+        int st = 0;
+        for (int sl = sb; sl < se; sl += SPB) {
+            const int st2 = st >= 1 ? st - 1 : 2;                // (st + 2) % 3
+            PG_STAMP(0)
+            const int nsl = min(SPB, se - sl);
+#if PG_H2_SPREAD
+            // the gathers of group i+2 ride inside this group's MFMA stream, one slab's worth between the two k-steps of each slab
+            // (a partial last group issues what is left in a burst: nothing of it is ever multiplied by this workgroup's range)
+            float* const ring2 = lds + st2 * SSTG;
+            const int s2 = sl + 2 * SPB;
+            auto issue_one = [&](int hf) { H2_ISSUE(ring2 + hf * STG, s2 + hf) };
+            PG_STAMP(1)
+            h_mma_group<TJ, RSD, TA, STG, SPB>(lds + st * SSTG, nsl, r, h, wm, bdw, bsh, acc, issue_one);
+            for (int hf = nsl; hf < SPB; ++hf) issue_one(hf);
+#else
+#pragma unroll
+            for (int hf = 0; hf < SPB; ++hf) H2_ISSUE(lds + st2 * SSTG + hf * STG, sl + 2 * SPB + hf)
             __builtin_amdgcn_sched_barrier(0);
-            h_mma_group<TJ, RSD, TA, STG>(lds + cur * SSTG, min(SPB, se - sl), r, h, wm, bdw, bsh, acc);
+            PG_STAMP(1)
+            h_mma_group<TJ, RSD, TA, STG, SPB>(lds + st * SSTG, nsl, r, h, wm, bdw, bsh, acc);
+#endif
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            PG_STAMP(2)
+            wait_landed(sl + 2 * SPB);
+            PG_STAMP(3)
+            st = st == 2 ? 0 : st + 1;
         }
+        __syncthreads();                                         // (drains the gathers issued past the range: the next tile restarts the ring)
+        PG_STAMP_FLUSH
 #undef H2_ISSUE
         if (sb == 0 && se == p.nslab) {
             if (TKIND) epilogue_t<S, MBW, NBW>(p, acc, m0, n0, lane, wm, wn);
@@ -177,8 +235,7 @@ template <int KW, int S, bool TK, int WM>
 hipError_t launch2(const IgemmParams& p, int grid, hipStream_t st) {
     constexpr int KWP = TK ? KW / S : KW, TJ = KWP < 32 ? KWP : 32, NQ = 32 / TJ, SC = TK ? 1 : S, TN = 64 * (8 / WM);
     constexpr int NI = (NQ * h2_rsd(SC, TN) / 4 + 63) / 64, STG = 128 * WM * 16 + NI * 256;
-    constexpr int SPB = 8 * STG * 4 <= H2_LDS ? 4 : (4 * STG * 4 <= H2_LDS ? 2 : 1);
-    constexpr int lds_bytes = 2 * SPB * STG * 4;
+    constexpr int lds_bytes = H2_RING * h2_spb(STG) * STG * 4;
     // (the attribute belongs to (function, current device): set on every call, nothing cached between calls)
     hipError_t e = hipFuncSetAttribute((const void*)conv_h2_kernel<KW, S, TK, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;

@@ -29,13 +29,15 @@ __device__ __forceinline__ void h_load_raw(const float* stage, int s, int r, int
         if (TJ >= 8) {
             const int qi = TJ == 32 ? 0 : (TJ == 16 ? s : 2 * s + h);
             const int tap0 = TJ == 32 ? 16 * s + 8 * h : (TJ == 16 ? 8 * h : 0);
-            const lds_u32 bp = Bd + qi * RSD + bdw[jb] + (tap0 >> 1);
-#pragma unroll
+            lds_u32 bp = Bd + qi * RSD + bdw[jb] + (tap0 >> 1);
+            asm volatile("" : "+v"(bp));        // ONE address per fragment: the five dwords then pair into ds_read2_b32 with 8-bit offsets
+#pragma unroll                                  // (folded into the stage constants, hipcc built an address per read pair)
             for (int i = 0; i < 5; ++i) f.d[jb][i] = bp[i];
         } else {
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                const lds_u32 bp = Bd + (4 * s + 2 * h + cc) * RSD + bdw[jb];
+                lds_u32 bp = Bd + (4 * s + 2 * h + cc) * RSD + bdw[jb];
+                asm volatile("" : "+v"(bp));
 #pragma unroll
                 for (int i = 0; i < 3; ++i) f.d[jb][3 * cc + i] = bp[i];
             }
@@ -72,28 +74,55 @@ __device__ __forceinline__ void h_mfma(const HRaw& f, const u32x4v (&b)[2], AccT
 // (even / odd k-steps, no copies): per k-step the ten LDS reads of the NEXT one are issued, then -- behind a scheduling fence --
 // the eight MFMAs of the current one, then the funnel shifts of the next one's B fragments, whose wait for the reads therefore
 // sits behind the MFMAs.  (The read past the last slab re-reads that slab: a valid address, never multiplied.)
-template <int TJ, int RSD, int TA, int STG>
+struct HNoIssue { __device__ __forceinline__ void operator()(int) const {} };
+
+// The 2 * nsl k-steps of nsl <= NSL consecutive slabs (LDS stages STG floats apart), fully unrolled over the slabs so that every
+// LDS read address is a per-lane base (set up once per group by the caller-independent prologue here) plus an IMMEDIATE -- with a
+// rolled slab loop hipcc spent one v_add per read (~32 VALU per slab, a third of a wave's non-MFMA issue time) -- and pipelined
+// one k-step deep on two register sets (even / odd k-steps, no copies): per k-step the ten LDS reads of the NEXT one are issued
+// between the first MFMAs of the current one and the funnel shifts of the next one's B fragments between its last MFMAs.
+// Instructions a wave issues BETWEEN its own MFMAs are free (an MFMA holds the vector issue for 8 of its 32 cycles); what a wave
+// issues outside its bursts is exposed once per iteration even with a partner wave on the SIMD (utilisation =
+// B / (B + t_n)).  `issue(hf)` is called once per slab, between its two k-steps: conv_h2.hip issues the gathers of slab hf of the
+// stage group two ahead there, so that its LDS-DMA instructions (60-185 cycles of issue each) sit inside the MFMA stream as well.
+// (The read past the last slab of the group re-reads that slab: a valid address, never multiplied.)
+template <int TJ, int RSD, int TA, int STG, int NSL, typename Issue = HNoIssue>
 __device__ __forceinline__ void h_mma_group(const float* stage0, int nsl, int r, int h, int wm, const int (&bdw)[2], const int (&bsh)[2],
-                                            AccT<4, 2>& acc) {
+                                            AccT<4, 2>& acc, const Issue& issue = Issue()) {
+    constexpr int NDS = 4 + 2 * (TJ >= 8 ? 3 : 4);          // LDS read instructions of a k-step
+#define H_INTERLEAVE                                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NDS - 8, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
     HRaw f0, f1;
     u32x4v b0[2], b1[2];
     h_load_raw<TJ, RSD, TA>(stage0, 0, r, h, wm, bdw, f0);
     h_finish<TJ>(f0, bsh, b0);
-#pragma unroll 1
-    for (int hf = 0; hf < nsl; ++hf) {
-        const float* st = stage0 + hf * STG;
-        const float* nx = hf + 1 < nsl ? st + STG : st;
-        h_load_raw<TJ, RSD, TA>(st, 1, r, h, wm, bdw, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        h_mfma(f0, b0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        h_finish<TJ>(f1, bsh, b1);
-        h_load_raw<TJ, RSD, TA>(nx, 0, r, h, wm, bdw, f0);
-        __builtin_amdgcn_sched_barrier(0);
-        h_mfma(f1, b1, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        h_finish<TJ>(f0, bsh, b0);
+#pragma unroll
+    for (int hf = 0; hf < NSL; ++hf) {
+        if (hf < nsl) {
+            const float* st = stage0 + hf * STG;
+            const float* nx = hf + 1 < NSL ? st + STG : st;
+            __builtin_amdgcn_sched_barrier(0);
+            h_load_raw<TJ, RSD, TA>(st, 1, r, h, wm, bdw, f1);
+            h_mfma(f0, b0, acc);
+            h_finish<TJ>(f1, bsh, b1);
+            H_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+            issue(hf);
+            __builtin_amdgcn_sched_barrier(0);
+            h_load_raw<TJ, RSD, TA>(nx, 0, r, h, wm, bdw, f0);
+            h_mfma(f1, b1, acc);
+            h_finish<TJ>(f0, bsh, b0);
+            H_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+#undef H_INTERLEAVE
 }
 
 }  // namespace

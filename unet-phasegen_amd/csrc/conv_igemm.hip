@@ -418,9 +418,9 @@ extern "C" int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, in
 // automatic tile family of pg_conv_fwd_h (measured on MI355X at the U-Net's layer shapes, tools/convh_bench.py)
 static int h_auto_variant(int kwp, int sc, long rows, long cols) {
     (void)rows; (void)cols;
-    // >= 8 taps per channel at unit window step, or 32: the wide 8-wave tile (D0, D1, U1, U0: +4 ... 7 %); short taps / stride-2
-    // windows (D2, D3, U2, U3), whose window bytes double with the tile width: the 4-wave 128 x 256 tile
-    return (kwp >= 32 || (kwp >= 8 && sc == 1)) ? 2 : 1;
+    // unit window step (every transposed conv; D1) or 32 taps per channel (D0): the wide 8-wave tile, +3 ... 7 % (U2 / U3: +5 / +3 %);
+    // stride-2 windows of short taps (D2, D3), whose window bytes double with the tile width: the 4-wave 128 x 256 tile
+    return (kwp >= 32 || sc == 1) ? 2 : 1;
 }
 
 static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, char* desc = nullptr, int desc_len = 0) {
