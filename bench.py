@@ -79,13 +79,11 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN_pmc_summary.json: FETCH_SIZE x2
     per the gfx950 correction + WRITE_SIZE, separate --pmc passes of this same command), else None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
-    for k, v in d.items():
-        if kernel + "(" in k and "hbm_read_bytes_corrected" in v:
-            return v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0), os.path.basename(files[-1])
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=lambda f: os.path.basename(f)[:3])
+    for f in reversed(files):                       # newest round first (r03.json, r03_e2e.json: one per profiled configuration)
+        for k, v in json.load(open(f)).items():
+            if kernel + "(" in k and "hbm_read_bytes_corrected" in v:
+                return v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0), os.path.basename(f)
     return None, None
 
 
@@ -167,6 +165,10 @@ def roofline_of(by, peak, step_tflops, precision, headline_shape):
     worst = min(big, key=lambda k: big[k]["frac"])
     d = by[dom]
     traffic, src = pmc_traffic(dom) if headline_shape and precision == "fp32" else (None, None)
+    if headline_shape:        # HBM-side bytes per launch (L2 fills + write-backs) of the five largest kernels, from the committed counters
+        for k in sorted(by, key=lambda k: -by[k]["ms_per_step"])[:5]:
+            t, tsrc = pmc_traffic(k)
+            by[k]["traffic"], by[k]["traffic_source"] = t, tsrc
     return {"bound": "mfma", "kernel": dom + " (" + ", ".join(d["layers"]) + ")",
             "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE)", "traffic_source": src,
@@ -438,7 +440,7 @@ def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf1
     fwd = lambda: model.engine.forward(polar[:, 0], update_stats=False, inference=True)
     fwd_ms = _timed(torch, dist, world, fwd, 2, max(steps, 5)) * 1e3
     ks, by = kernel_pass(torch, ops, fwd, 3, fl, peak, fwd_ms)
-    roof = roofline_of(by, peak, sum(fl.values()) / (fwd_ms * 1e-3) / 1e12, prec, False)
+    roof = roofline_of(by, peak, sum(fl.values()) / (fwd_ms * 1e-3) / 1e12, prec, clips == 32)
     roof["step_frac_of"] = ("U-Net forward stage (input cast + 8 convs + 6 BatchNorms), timed clean: all conv FLOPs / stage time / peak; "
                             "by_kernel holds per-launch event times (an event pair per launch reads a few % longer than the clean loop)")
     dom = roof["kernel"].split(" (")[0]

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (gpurun_out/..., scratch) into the small, committed files under profiles/.
 
-    python profiles/summarize_pmc.py r01 gpurun_out/prof_r01b gpurun_out/pmc_r01b_fetch gpurun_out/pmc_r01b_write gpurun_out/pmc_r01b_sq
+    python profiles/summarize_pmc.py r03 gpurun_out/prof_r03_train gpurun_out/pmc_r03_train_FETCH_SIZE gpurun_out/pmc_r03_train_WRITE_SIZE ...
+    (normally through  bash profiles/collect.sh --summarize r03)
 
   <tag>_kernel_stats.csv   verbatim `rocprofv3 --kernel-trace --stats` per-kernel table
   <tag>_pmc_summary.json   mean counter value per dispatch and kernel; FETCH_SIZE / WRITE_SIZE (KB) converted to
@@ -51,6 +52,9 @@ def main():
             d["hbm_read_bytes_corrected"] = d["FETCH_SIZE_mean_per_dispatch"] * 1024 * 2
         if "WRITE_SIZE_mean_per_dispatch" in d:
             d["hbm_write_bytes"] = d["WRITE_SIZE_mean_per_dispatch"] * 1024
+        h, m = d.get("TCC_HIT_sum_mean_per_dispatch"), d.get("TCC_MISS_sum_mean_per_dispatch")
+        if h is not None and m is not None and h + m > 0:
+            d["l2_hit_rate"] = h / (h + m)
         out[k] = d
     json.dump(out, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print("wrote", tag, len(out), "kernels")

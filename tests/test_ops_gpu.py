@@ -39,16 +39,21 @@ GEOMS = [
     # k = 5, s = 2 beyond the U-Net's own use (transposed, even channel counts): as a Conv1d, with odd channel counts (the F
     # form then stays on the im2col kernel), with enough columns for several tiles and samples per tile
     (False, 34, 20, 5, 2, 1, 31, 3), (False, 33, 70, 5, 2, 2, 17, 2), (True, 36, 17, 5, 2, 1, 9, 2), (True, 72, 140, 5, 2, 1, 30, 9),
+    # frame counts at which the wgrad takes the per-sample-slab kernel (padding a sample to whole 16-frame slabs costs <= 7 %):
+    # 61 and 30 frames of dy / x for the stride-2 families, several samples, ragged channel counts
+    (False, 40, 70, 8, 2, 1, 126, 3), (False, 36, 72, 4, 2, 1, 61, 5), (True, 72, 40, 8, 2, 1, 61, 3), (False, 24, 136, 8, 1, 2, 33, 4),
 ]
 
 
-@pytest.fixture(params=[1, 2, 5, 6, 10], ids=["raw/tile-per-wg", "raw/stream-k", "im2col/tile-per-wg", "im2col/stream-k", "raw-wide-only/stream-k"])
+@pytest.fixture(params=[1, 2, 5, 6, 10, 128 | 2], ids=["raw/tile-per-wg", "raw/stream-k", "im2col/tile-per-wg", "im2col/stream-k", "raw-wide-only/stream-k",
+                                                      "flat-K-wgrad/stream-k"])
 def schedule(request):
     """Run the conv tests under both work decompositions (one whole tile per workgroup; the persistent stream-K split
     with partial tiles through the workspace + fixup kernel, which the library otherwise only picks for tile counts
     that quantise badly over the CUs) and with the raw-window F/T kernels enabled or disabled (bit 2), so the im2col
     kernels they normally replace stay covered; bit 3 keeps the small problems of this file on the wide 128 x 256 raw tile
-    (they otherwise take the tall 256 x 128 one), so both tile shapes see every geometry."""
+    (they otherwise take the tall 256 x 128 one), so both tile shapes see every geometry; bit 7 keeps the wgrad on the flat-K kernel
+    where it would take the per-sample-slab one."""
     from phasegen import ops
     ops.set_conv_schedule(request.param)
     yield request.param

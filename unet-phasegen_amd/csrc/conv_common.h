@@ -24,6 +24,7 @@ struct IgemmParams {
     int LP; float inv_LP;            // G: frames of P and 1/LP
     int a_vec;                       // F: weight rows may be read as aligned float4
     int tilesM, tilesN;
+    int g_ps;                        // G: 1 = per-sample slabs (conv_g_ps_kernel): K = B * ceil(LP / 16) slabs of 16 frames of one sample
     int tn_stride;                   // columns between the origins of consecutive column tiles (= tile width; k = 5 wgrad: 255 of 256)
     float* y2; long y2_bs; float y_slope, y2_slope;   // F,T fwd: activation on store, optional second output
     float* ws;                       // stream-K partial-tile workspace: [grid][2][64][256] floats (or NULL)

@@ -92,18 +92,20 @@ struct Knobs {
     int no_tall;      // 1 = never use the tall 256 x 128 raw tile
     int oversub;      // stream-K grid = up to oversub x resident workgroup slots
     int contended;    // other kernels (RCCL collectives) are expected to hold part of the chip: always take the finer split
+    int no_ps;        // wgrad: 1 = never the per-sample-slab kernel (A/B, tests)
     int hvar;         // pg_conv_fwd_h only: tile family, 0 automatic, 1 = 128 x 256 (4 waves), 2 = 128 x 512, 3 = 256 x 256 (8 waves)
     char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
 };
 int decode_knobs(const pg_conv_args* a, Knobs& k) {
     if (a->precision < 0 || a->precision > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv: precision must be PG_PREC_FP32, PG_PREC_BF16 or PG_PREC_BF16X3");
     const int sc = a->schedule;
-    if (sc < 0 || (sc & ~0xf7f) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
+    if (sc < 0 || (sc & ~0xfff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
     k.prec = a->precision;
     k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
     k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
     k.contended = (sc >> 4) & 1;
     k.hvar = (sc >> 5) & 3;
+    k.no_ps = (sc >> 7) & 1;
     k.desc = nullptr; k.desc_len = 0;
     return PG_OK;
 }
@@ -190,6 +192,13 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     int bn = tall ? RBN / 2 : (raw ? RBN : BN);
     const bool k5 = raw && p.k == 5 && p.s == 2;
     if (k5 && kind == KIND_G) bn = (RBN / 5) * 5;               // wgrad: a column tile is 51 whole channels x 5 taps = 255 columns (+ 1 idle)
+    p.g_ps = 0;
+    if (raw && kind == KIND_G && p.k != 32) {
+        // short samples: slabs of 16 frames of ONE sample (conv_g_ps_kernel) where padding every sample to whole slabs costs <= 7 %
+        // of MFMA work (30 frames: 6.7 %, 61: 4.9 %, 126: 1.6 %, 256: none; 129 would cost 11.6 % and keeps the flat K axis)
+        const long cps = (p.LP + 15) / 16;
+        if ((cps * 16 - p.LP) * 100 <= 7L * p.LP && !kn.no_ps) { p.g_ps = 1; Ktot = (long)p.B * cps * 16; }
+    }
     if (k5 && kind != KIND_G) Ktot = (long)p.Q * (kind == KIND_T ? 4 : 8);   // F / T: K runs over the virtual taps
     p.tn_stride = bn;
     p.tilesM = (int)((rows + bm - 1) / bm);
@@ -203,7 +212,7 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     if (kn.desc) {      // the kernel this call would launch, named as rocprofv3 names it (profiles/*_kernel_stats.csv)
         const bool spec = (p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || (p.k == 5 && p.s == 2);
         char name[96];
-        if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_raw_kernel<%d, %d, %d>", p.k, p.s, kn.prec);
+        if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_%s_kernel<%d, %d, %d>", p.g_ps ? "ps" : "raw", p.k, p.s, kn.prec);
         else if (raw) snprintf(name, sizeof name, "conv_raw_kernel<%d, %d, %s, %d, %d>", p.k, p.s, kind == KIND_T ? "true" : "false", kn.prec, tall ? 1 : 2);
         else snprintf(name, sizeof name, "conv_%c_kernel<%d, %d, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), spec ? p.k : 0, spec ? p.s : 0, kn.prec);
         snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", name, grid, tiles, p.nslab, (int)split, p.whole);

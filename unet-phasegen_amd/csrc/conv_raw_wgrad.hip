@@ -232,8 +232,178 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Per-sample slabs (round 3): the variant for SHORT samples.  Above, a slab is 16 consecutive (b, i) of the flattened K axis:
+// with 30 frames per sample every other slab runs over a sample boundary, and almost every remaining one has its window partly
+// outside the row, so the 2 + 2 wide gathers of the fast path are the exception and 8 + 2 x 8 dword gathers (~2400 issue cycles
+// beside 4096 of MFMA) the rule: 62-69 % of the fp32 pipe at the U-Net's bottleneck.  Here a slab is 16 consecutive frames of ONE
+// sample, the last slab of a sample padded (K = B * ceil(LP / 16) * 16: + 6.7 % MFMA work at 30 frames, + 4.9 % at 61, + 1.6 % at
+// 126; the host only takes this kernel where that is <= 7 %).  Then EVERY slab gathers with the wide pieces and no range checks:
+//   P tile:   frames gi .. gi + 15 of the rows, 16-byte pieces (frames past LP are the next row's: the A fragments of k >= LP - gi
+//             are zeroed in registers, one wave-uniform branch per slab);
+//   windows:  positions s gi - p + [0, WLP) of every channel as 16-byte pieces; positions outside [0, Lx) hold a neighbouring
+//             row's values (or zeros past the tensor): on slabs whose window leaves the row -- wave-uniform -- the B fragment
+//             elements are range-checked and zeroed in registers (64 VALU beside 64 MFMAs).
+// Zeroing is a select, not a product: every operand that reaches the matrix pipe is real data or 0.  The only gather whose
+// offset could become negative -- channel 0's first pieces, p positions in front of the tensor's first row -- is dropped from
+// the wide gathers and re-loaded element-wise by ONE extra dword instruction of wave 0 (tiles with qbase == 0 only).
+// ----------------------------------------------------------------------------------------------------------------
+template <int KW, int S, int BF>
+__global__ __launch_bounds__(NT, 2) void conv_g_ps_kernel(const IgemmParams p) {
+    using C = GRaw<KW, S>;
+    constexpr int STG = RTILE_A + (C::SUB + 255) / 256 * 256;          // window image rounded up to whole 16-byte wave instructions
+    constexpr int NE16 = (C::SUB / 4 + NT - 1) / NT;
+    static_assert(C::WLP % 4 == 0 && C::WLP <= 64, "16-byte window pieces; channel 0 inside the first 64 floats");
+    __shared__ __attribute__((aligned(16))) float lds[2 * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wv >> 1, wn = wv & 1;
+    const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
+    const float slopeA = act_slope(p.act_p), slopeB = act_slope(p.act_x);
+    const int pbs4 = (int)p.pt_bs * 4, xbs4 = (int)p.x_bs * 4;
+    const int cps = (p.LP + 15) >> 4;                                  // slabs (chunks of 16 frames) per sample
+    const int g = logical_wg(blockIdx.x, gridDim.x, p.whole);
+    const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, gridDim.x, p.whole);
+    int pos = split_lo(sp, g);
+    const int pos_end = split_lo(sp, g + 1);
+    int slot = 0;
+    while (pos < pos_end) {
+        const int tile = pos / p.nslab, sb = pos - tile * p.nslab;
+        const int se = min(p.nslab, sb + (pos_end - pos));
+        const int m0 = (tile / p.tilesN) * RBM, n0 = (tile % p.tilesN) * C::TNV;
+        const int qbase = (tile % p.tilesN) * C::NQT;
+
+        int pv[2], woff[NE16];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int m = m0 + dma16_row(lane, wv, e);
+            pv[e] = m < p.M ? (m * p.LP + dma16_kc(lane)) * 4 : FAR;
+        }
+#pragma unroll
+        for (int e = 0; e < NE16; ++e) {
+            const int f = 4 * (tid + NT * e), ql = f / C::WLP, v0 = f - ql * C::WLP;
+            const int off = ((qbase + ql) * p.Lx + v0 - p.p) * 4;         // >= 0 except for channel 0's pieces in front of the tensor
+            woff[e] = (f < C::SUB && qbase + ql < p.Q && off >= 0) ? off : FAR;
+        }
+        // wave 0's element-wise reload of the first 64 floats of the image (channel 0 and the start of channel 1) on tiles that hold channel 0
+        const bool fix0 = qbase == 0 && wv == 0;
+        int f0_off, f0_v;
+        { const int ql = lane / C::WLP, v = lane - ql * C::WLP; f0_off = ql < p.Q ? ql * p.Lx * 4 : FAR; f0_v = v - p.p; }
+        int bbase[4], pj[4];                           // fragment base of this lane's 4 columns; their window position at slab element 0
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int c = wn * 128 + jb * 32 + (lane & 31), qc = c / KW;
+            bbase[jb] = qc * C::WLP + (c - qc * KW) + S * 8 * (lane >> 5);
+            pj[jb] = (c - qc * KW) + S * 8 * (lane >> 5) - p.p;
+        }
+        AccR acc;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc.c[i][j][r] = 0.f;
+
+        int gb = sb / cps, gc = sb - gb * cps;          // (sample, chunk) of the slab being GATHERED (one ahead of the multiplied one)
+#define GPS_ISSUE(STAGE_PTR)                                                                              \
+    {   float* const As = (STAGE_PTR) + wv * 64;                                                          \
+        if (gb < p.B) {                                                                                   \
+            const int gi = gc << 4;                                                                       \
+            const int sa = gb * pbs4 + gi * 4;                                                            \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) dma16s(rp, As + wv * 192 + e * 1024, pv[e], sa); \
+            const int sw_ = gb * xbs4 + S * gi * 4;                                                       \
+            _Pragma("unroll") for (int e = 0; e < NE16; ++e)                                              \
+                if (4 * (e * NT + wv * 64) < C::SUB) dma16s(rx, (STAGE_PTR) + RTILE_A + 4 * (e * NT + wv * 64), woff[e], sw_); \
+            if (fix0) {                                                                                   \
+                const int ps = S * gi + f0_v;                                                             \
+                dma4(rx, (STAGE_PTR) + RTILE_A, (unsigned)ps < (unsigned)p.Lx ? gb * xbs4 + f0_off + ps * 4 : FAR); \
+            }                                                                                             \
+        }                                                                                                 \
+        if (++gc == cps) { gc = 0; ++gb; }                                                                \
+    }
+        int mb = gb, mc = gc;                           // (sample, chunk) of the slab being MULTIPLIED
+        GPS_ISSUE(lds)
+        __syncthreads();
+        for (int sl = sb; sl < se; ++sl) {
+            const int cur = (sl - sb) & 1;
+            GPS_ISSUE(lds + (cur ^ 1) * STG)
+            __builtin_amdgcn_sched_barrier(0);
+            {   // fragments + MFMA for slab sl = (mb, mc)
+                const float* As = lds + cur * STG;
+                const float* Bw = As + RTILE_A;
+                const int r = lane & 31, h = lane >> 5, sw = (r >> 2) & 3;
+                const float* ap = As + (wm * 64 + r) * BK;
+                const int gi = mc << 4, kc = p.LP - gi;              // valid frames of this slab (>= 16: all)
+                const int w0 = S * gi;                               // window element v sits at row position w0 + v - p
+                f32x4 a[2][2];
+                float b[4][8];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) b[jb][i] = Bw[bbase[jb] + S * i];
+                if (kc < 16) {                          // the sample's last, padded slab: frames past LP are not this row's
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) a[i][c][v] = (8 * h + 4 * c + v < kc) ? a[i][c][v] : 0.f;
+                }
+                if (w0 < p.p || w0 - p.p + C::WLP > p.Lx) {   // the window leaves the row: zero what lies outside [0, Lx)
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) b[jb][i] = (unsigned)(w0 + pj[jb] + S * i) < (unsigned)p.Lx ? b[jb][i] : 0.f;
+                }
+                if (slopeA != 1.0f) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) a[i][c][v] = act_apply(a[i][c][v], slopeA);
+                }
+                if (slopeB != 1.0f) {
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) b[jb][i] = act_apply(b[jb][i], slopeB);
+                }
+                if (BF) mfma_low_2x4<BF>(a, b, acc);
+                else {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk], acc.c[i][j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (++mc == cps) { mc = 0; ++mb; }
+            __syncthreads();
+        }
+#undef GPS_ISSUE
+        (void)mb;
+        if (sb == 0 && se == p.nslab) epilogue_g<S, 2, 4>(p, acc, m0, n0, lane, wm, wn, n0 + C::TNV);
+        else store_partial(p.ws, g, slot, acc, tid);
+        pos += se - sb;
+        slot = 1;
+    }
+}
+
 template <int KW, int S>
 hipError_t launch_g_raw(const IgemmParams& p, int grid, hipStream_t st, int prec) {
+    if (p.g_ps) {        // per-sample slabs (host: short samples whose padded K costs <= 7 %)
+        if (prec == 1) hipLaunchKernelGGL((conv_g_ps_kernel<KW, S, 1>), dim3(grid), dim3(NT), 0, st, p);
+        else if (prec == 2) hipLaunchKernelGGL((conv_g_ps_kernel<KW, S, 2>), dim3(grid), dim3(NT), 0, st, p);
+        else hipLaunchKernelGGL((conv_g_ps_kernel<KW, S, 0>), dim3(grid), dim3(NT), 0, st, p);
+        return hipGetLastError();
+    }
     if (prec == 1) hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, 1>), dim3(grid), dim3(NT), 0, st, p);
     else if (prec == 2) hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, 2>), dim3(grid), dim3(NT), 0, st, p);
     else hipLaunchKernelGGL((conv_g_raw_kernel<KW, S, 0>), dim3(grid), dim3(NT), 0, st, p);

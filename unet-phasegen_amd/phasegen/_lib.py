@@ -15,6 +15,7 @@ PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2           # pg_conv_args.precision
 OK, ERR_NULL, ERR_SHAPE, ERR_ALIGN, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4, -5   # return codes (PG_ERR_*)
 OP_CONV1D_FWD, OP_CONV1D_DGRAD, OP_CONV1D_WGRAD, OP_CONVT1D_FWD, OP_CONVT1D_DGRAD, OP_CONVT1D_WGRAD = range(6)   # pg_conv_describe
 SCHED_AUTO, SCHED_TILE_PER_WG, SCHED_FORCE_STREAMK, SCHED_NO_RAW, SCHED_NO_TALL, SCHED_CONTENDED = 0, 1, 2, 4, 8, 16   # pg_conv_args.schedule bits
+SCHED_NO_PS = 128      # wgrad: keep the flat-K raw kernel (no per-sample slabs)
 SCHED_H_128x256, SCHED_H_128x512, SCHED_H_256x256 = 32, 64, 96   # pg_convh_args.schedule bits 5-6: tile family of pg_conv_fwd_h (0 = automatic)
 
 c_float_p = C.c_void_p  # device pointers travel as integers

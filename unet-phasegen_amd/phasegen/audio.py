@@ -74,8 +74,8 @@ def griffin_lim_batch(mag, n_fft, hop_length, n_iter, init=None, seed=None):
     Every iteration is four launches whatever n is -- STFT (pg_stft) -> keep phase, impose magnitude (pg_gl_project) -> the
     2046-point inverse transform as ONE 1x1 convolution on the fp32-MFMA conv kernel (batch axis = clips) -> overlap-add
     (pg_ola_nt) -- and clip c's result is bit-identical to running it alone (no kernel reduces across clips).
-    ``init``: (n, hop * (frames - 1)) start signals; else clip c starts from N(0, 1) drawn with seed ``seed + c`` (replaces
-    ``np.random.randn``, utils.py:116).  Returns device tensors (audio (n, length) peak-normalised per clip, new_spec
+    ``init``: (n, hop * (frames - 1)) start signals; else clip c starts from N(0, 1) drawn with seed ``seed + c`` (or ``seed[c]``
+    when a list is given; replaces ``np.random.randn``, utils.py:116).  Returns device tensors (audio (n, length) peak-normalised per clip, new_spec
     (n, 2, bins, frames) = [re; im] of the last projection, loss (n,))."""
     dev = _dev()
     if not (torch.is_tensor(mag) and mag.is_cuda and mag.dtype == torch.float32 and mag.dim() == 3):
@@ -86,11 +86,17 @@ def griffin_lim_batch(mag, n_fft, hop_length, n_iter, init=None, seed=None):
         raise ValueError(f"griffin_lim: spec has {bins} rows, expected n_fft/2 = {n_fft // 2}")
     length = hop_length * (frames - 1)
     if init is None:
-        base = torch.initial_seed() if seed is None else seed
+        if isinstance(seed, (list, tuple)):                     # one seed per clip
+            seeds = list(seed)
+            if len(seeds) != n:
+                raise ValueError("griffin_lim_batch: one seed per clip expected")
+        else:
+            base = torch.initial_seed() if seed is None else seed
+            seeds = [base + c for c in range(n)]
         rows = []
-        for c in range(n):
+        for sd in seeds:
             g = torch.Generator(device="cpu")
-            g.manual_seed(base + c)
+            g.manual_seed(sd)
             rows.append(torch.randn(length, generator=g, dtype=torch.float64))
         init = torch.stack(rows).to(torch.float32)
     audio = torch.empty(n, length, device=dev)
@@ -115,7 +121,8 @@ def griffin_lim_batch(mag, n_fft, hop_length, n_iter, init=None, seed=None):
             prev.copy_(recon)
             ops.ola_nt(fr, hop_length, recon)
         if n_iter > 0:
-            loss[c0:c1] = torch.sqrt(torch.sum((recon - prev) ** 2, dim=1) / length)
+            for c in range(m):          # one 1-D reduction per clip: the summation order does not depend on how many clips run together
+                loss[c0 + c] = torch.sqrt(torch.sum((recon[c] - prev[c]) ** 2) / length)
         peak = recon.abs().amax(dim=1, keepdim=True)
         audio[c0:c1] = torch.where(peak > torch.finfo(torch.float32).tiny, recon / peak, recon)
     return audio, new_spec, loss

@@ -12,21 +12,38 @@ from . import audio
 
 
 @torch.no_grad()
-def validation_metrics(model, val_batch, hop_length=512, n_fft=2048, gl_iters=250, gl_seed=0):
+def validation_metrics(model, val_batch, hop_length=512, n_fft=2048, gl_iters=250, gl_seed=0, group=None, shard=False):
     """val_batch: (n, 2, bins, frames) = [logmag; angle] on the device.  Returns {"MSE", "NOPMSE", "LMSE"} floats.
     Nothing leaves the device before the three means: the forwards are batch-of-one (train-mode BatchNorm, train.py:76: the
     statistics of a clip must not see the others), everything else -- the three ISTFTs and the Griffin-Lim comparator -- is
-    batched over the clips."""
+    batched over the clips.
+    ``shard=True`` (data-parallel training; EVERY rank of ``group`` must call it with the same batch): rank r evaluates clips
+    r::W and the sums are all-reduced, so no rank sits in the next gradient all-reduce while another one validates, and the
+    250 Griffin-Lim iterations run on W GPUs.  Clip c draws its Griffin-Lim start with seed gl_seed + c on whichever rank it
+    lands: the result does not depend on W (up to the order of the final fp32 sums)."""
+    import torch.distributed as dist
     val_batch = val_batch.contiguous()
     n, _, bins, _ = val_batch.shape
-    logmag, ang = val_batch[:, 0].contiguous(), val_batch[:, 1].contiguous()
-    phase = torch.empty_like(logmag)
-    for c in range(n):
-        phase[c] = model.forward(val_batch[c:c + 1, 0])[0, :bins]       # batch of one, train-mode BN (train.py:76)
-    orig = audio.synthesize(logmag, ang, hop_length)
-    hyb = audio.synthesize(logmag, phase, hop_length)
-    nop = audio.synthesize(logmag, torch.zeros_like(logmag), hop_length)
-    lim, _, _ = audio.griffin_lim_batch(torch.exp(logmag) - 1.0, n_fft, hop_length, gl_iters, seed=gl_seed)
-    # (clips have equal length: the mean over everything == the reference's mean of per-clip means)
-    res = torch.stack([torch.abs(orig - hyb).mean(), torch.abs(orig - nop).mean(), torch.abs(orig - lim).mean()]).cpu()
+    world = dist.get_world_size(group) if (shard and dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    mine = list(range(rank, n, world))
+    sums = torch.zeros(4, device=val_batch.device, dtype=torch.float64)           # sum |orig - hyb|, |orig - nop|, |orig - lim|, elements
+    if mine:
+        vb = val_batch[mine]
+        logmag, ang = vb[:, 0].contiguous(), vb[:, 1].contiguous()
+        phase = torch.empty_like(logmag)
+        for i in range(len(mine)):
+            phase[i] = model.forward(vb[i:i + 1, 0])[0, :bins]                   # batch of one, train-mode BN (train.py:76)
+        orig = audio.synthesize(logmag, ang, hop_length)
+        hyb = audio.synthesize(logmag, phase, hop_length)
+        nop = audio.synthesize(logmag, torch.zeros_like(logmag), hop_length)
+        lim, _, _ = audio.griffin_lim_batch(torch.exp(logmag) - 1.0, n_fft, hop_length, gl_iters, seed=[gl_seed + c for c in mine])
+        sums[0] = torch.abs(orig - hyb).double().sum()
+        sums[1] = torch.abs(orig - nop).double().sum()
+        sums[2] = torch.abs(orig - lim).double().sum()
+        sums[3] = orig.numel()
+    if world > 1:
+        dist.all_reduce(sums, group=group)
+    # (clips have equal length: the mean over everything == the reference's mean of per-clip means, train.py:122)
+    res = (sums[:3] / sums[3]).cpu()
     return {"MSE": float(res[0]), "NOPMSE": float(res[1]), "LMSE": float(res[2])}

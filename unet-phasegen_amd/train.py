@@ -72,7 +72,7 @@ def main():
     if a.resume:
         trainer.load_checkpoint(a.resume)
     val_loader = None
-    if not a.synthetic and os.path.exists(a.val) and rank == 0:
+    if not a.synthetic and os.path.exists(a.val):           # every rank: validation is sharded over the ranks (validate.py)
         val_loader = get_fft_npy_loader([a.val], [0, 1], batch_size=a.val_clips, precon=True, seed=0)
     os.makedirs(a.log_dir, exist_ok=True)
     log = open(os.path.join(a.log_dir, "log.jsonl"), "a") if rank == 0 else None
@@ -94,10 +94,13 @@ def main():
             n_loss += 1
             frames += d[0].size(0) * d[0].size(3) * world
             if cnt % a.val_every == 0 and val_loader is not None:              # train.py:69-124 (metrics only, JSONL)
-                vm = validation_metrics(model, val_loader.__iter__().__next__()[0], a.hop, a.n_fft, a.gl_iters)
+                # at a step boundary, on EVERY rank (same seed -> same first batch everywhere): rank r takes clips r::W, the sums
+                # are all-reduced -- nobody waits in the next gradient all-reduce while rank 0 runs 250 Griffin-Lim iterations
+                vm = validation_metrics(model, val_loader.__iter__().__next__()[0], a.hop, a.n_fft, a.gl_iters, shard=world > 1)
                 vm["steps"] = cnt
-                log.write(json.dumps(vm) + "\n")
-                log.flush()
+                if rank == 0:
+                    log.write(json.dumps(vm) + "\n")
+                    log.flush()
             if cnt % a.ckpt_every == 0 and rank == 0:
                 trainer.save_checkpoint(a.log_dir + "/ckpt_{}".format(cnt))   # train.py:126-127 (+ optimiser state)
             if a.max_steps and cnt >= a.max_steps:
