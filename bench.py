@@ -439,6 +439,13 @@ def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf1
     # host's launch latency after every synchronize and reads ~10 % long); this is the time the roofline fraction is taken on
     fwd = lambda: model.engine.forward(polar[:, 0], update_stats=False, inference=True)
     fwd_ms = _timed(torch, dist, world, fwd, 2, max(steps, 5)) * 1e3
+    graph_ms = None
+    if prec == "bf16":      # the same forward replayed from a captured HIP graph: 8 convs + fixups + 6 BatchNorms, one launch
+        model.engine.graphs = True
+        try:
+            graph_ms = _timed(torch, dist, world, fwd, 3, max(steps, 5)) * 1e3
+        finally:
+            model.engine.graphs = False
     ks, by = kernel_pass(torch, ops, fwd, 3, fl, peak, fwd_ms)
     roof = roofline_of(by, peak, sum(fl.values()) / (fwd_ms * 1e-3) / 1e12, prec, clips == 32)
     roof["step_frac_of"] = ("U-Net forward stage (input cast + 8 convs + 6 BatchNorms), timed clean: all conv FLOPs / stage time / peak; "
@@ -453,7 +460,7 @@ def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf1
         "config": {"workload": f"BASELINE configs[4]: {clips} stereo clips x {n} samples per rank, 2048-FFT / 512-hop, "
                                f"STFT+polar -> UNetModel({C}, {2 * C}).forward -> ISTFT", "signals_per_rank": nsig, "frames": frames},
         "stage_ms": {"stft+polar": stage[0] / 3, "unet_forward": fwd_ms, "istft": stage[2] / 3,
-                     "unet_forward_event_bracketed": stage[1] / 3},
+                     "unet_forward_event_bracketed": stage[1] / 3, "unet_forward_graph_replay": graph_ms},
         "roofline": roof, "kernels": ks}
 
 

@@ -131,6 +131,31 @@ def test_bf16_shadows_follow_in_place_parameter_writes_by_torch():
         assert torch.equal(model.forward(x[:, 0]), y2)
 
 
+@pytest.mark.parametrize("B,L,update", [(1, 128, False), (5, 64, True)])
+def test_resident_forward_graph_replay_equals_eager(B, L, update):
+    """engine.graphs: the bf16-resident inference forward behind the input cast is captured into a HIP graph on its second call at
+    a shape and replayed afterwards.  Replays must be bit-identical to the eager launch sequence, follow new inputs and new
+    weights (the shadows are rebuilt in place), and keep counting BatchNorm statistics when asked to."""
+    from phasegen.model import UNetModel
+    C = 64
+    torch.manual_seed(3)
+    m = UNetModel(C, 2 * C, precision="bf16")
+    eng = m.engine
+    xs = [torch.from_numpy(detgen.make_batch(B, C, L, seed=40 + i))[:, 0].contiguous().cuda() for i in range(4)]
+    want = [eng.forward(x, update_stats=False, inference=True).clone() for x in xs]
+    nb0 = int(eng.arena.buffers[detgen.BN_KEYS[0] + ".num_batches_tracked"])
+    eng.graphs = True
+    got = [eng.forward(x, update_stats=update, inference=True).clone() for x in xs]       # eager, capture + replay, replay, replay
+    assert all(torch.equal(g, w) for g, w in zip(got, want))
+    assert isinstance(eng.plans[("graph", B, L, update)], torch.cuda.CUDAGraph)
+    assert int(eng.arena.buffers[detgen.BN_KEYS[0] + ".num_batches_tracked"]) == nb0 + (4 if update else 0)
+    with torch.no_grad():
+        next(iter(m.parameters())).mul_(0.5)                   # new weights: the replay must see the rebuilt shadows
+    y_new = eng.forward(xs[0], update_stats=update, inference=True).clone()
+    eng.graphs = False
+    assert torch.equal(y_new, eng.forward(xs[0], update_stats=False, inference=True)) and not torch.equal(y_new, want[0])
+
+
 def test_resident_forward_falls_back_where_windows_do_not_fit():
     """Many very short samples per 256-column tile (B = 64 clips of 24 frames) exceed the bf16-resident kernels' window
     slots: the engine must notice BEFORE launching anything (pg_conv_fwd_h_supported) and run the fp32-tensor kernels with

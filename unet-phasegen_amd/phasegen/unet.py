@@ -137,6 +137,7 @@ class UNetEngine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         # MFMA operand mode of every conv of this engine (pg_conv_args.precision); None = the calling thread's default
         self.precision = None if precision is None else ops.precision_code(precision)
+        self.graphs = False          # True: the bf16-resident inference forward replays a captured HIP graph per (batch, frames)
         self.contended = False       # True (set by the data-parallel Trainer): RCCL's kernels share the chip during backward ->
         #                              backward convs keep the fine stream-K split (pg_conv_args.schedule, PG_SCHED_CONTENDED)
         self.fwd_count = 0           # forward passes so far: backward() refers to the LAST one (checked by the autograd node)
@@ -250,13 +251,38 @@ class UNetEngine:
     def _forward_resident(self, x, update_stats):
         """Forward with bf16-resident operands: every activation a conv reads lives in HBM as bf16 (written activated by the
         producing conv epilogue / BatchNorm), weights come from bf16 shadows, BatchNorm statistics and outputs stay fp32.
-        No tensors are kept for backward: inference only."""
+        No tensors are kept for backward: inference only.  With ``self.graphs`` the launch sequence behind the input cast (8 convs
+        with their fixups + 6 BatchNorms) is captured once per (batch, frames, update_stats) into a HIP graph and replayed: every
+        buffer it touches is a plan buffer, the weight shadows included (rebuilt IN PLACE when the parameters change)."""
         B, C, L = x.shape
         plan = self._plan_h(B, L)
         f = plan["fwd"]
-        L, L1, L2, L3, L4 = plan["L"]
-        h = 2 * C
         sh = self._shadows()
+        ops.cast_rows_bf16(x, f["x0"])
+        if not self.graphs or ops._timer is not None:
+            self._resident_body(plan, sh, update_stats)
+        else:
+            key = ("graph", B, L, bool(update_stats))
+            g = self.plans.get(key)
+            if g is None:                        # first forward at this shape: eager (creates the workspaces the graph will reference)
+                self._resident_body(plan, sh, update_stats)
+                self.plans[key] = "warm"
+            else:
+                if g == "warm":                  # second: capture -- nothing executes while capturing -- then replay as this call's forward
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._resident_body(plan, sh, update_stats)
+                    self.plans[key] = g
+                g.replay()
+        self.fwd_count += 1
+        self.cur = None                      # nothing kept for backward
+        return f["out"]
+
+    def _resident_body(self, plan, sh, update_stats):
+        f = plan["fwd"]
+        L, L1, L2, L3, L4 = plan["L"]
+        C = self.C
+        h = 2 * C
         a = self.arena
 
         def conv(name, xh, Lin, **out):
@@ -273,7 +299,6 @@ class UNetEngine:
             if update_stats:
                 a.buffers[key + ".num_batches_tracked"] += 1
 
-        ops.cast_rows_bf16(x, f["x0"])
         conv("D0", f["x0"], L, yh=f["l0"], yh_act=ACT_LEAKY, yh2=f["cat0"][:, :h], yh2_act=ACT_RELU)
         conv("D1", f["l0"], L1, y=f["c1"])
         bn("D1", f["c1"], yh=f["l1"], yh_act=ACT_LEAKY, yh2=f["cat1"][:, :h], yh2_act=ACT_RELU)
@@ -288,9 +313,6 @@ class UNetEngine:
         bn("U1", f["r1"], yh=f["cat0"][:, h:], yh_act=ACT_RELU)
         conv("U0", f["cat0"], L1, y=f["r0"])
         bn("U0", f["r0"], y=f["out"])
-        self.fwd_count += 1
-        self.cur = None                      # nothing kept for backward
-        return f["out"]
 
     # -- forward -----------------------------------------------------------------------------------------------
     def forward(self, x, update_stats=True, inference=False):
