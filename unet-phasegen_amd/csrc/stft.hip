@@ -13,6 +13,10 @@
 #include "phasegen.h"
 #include "pg_common.h"
 
+#ifndef PG_STFT_ABL
+#define PG_STFT_ABL 0
+#endif
+
 namespace {
 
 constexpr int FFT_THREADS = 256;
@@ -209,6 +213,10 @@ __device__ __forceinline__ void stft_store_row(const pg_stft_args& a, float* o_r
     }
     float* pr = o_re + row * a.n_frames;
     float* pi = o_im + row * a.n_frames;
+#if PG_STFT_ABL == 1    /* dev-only: everything but the global stores (values kept alive) */
+    asm volatile("" :: "v"(re[0]), "v"(re[1]), "v"(re[2]), "v"(re[3]), "v"(im[0]), "v"(im[1]), "v"(im[2]), "v"(im[3]), "v"(pr), "v"(pi));
+    return;
+#endif
     if (vec) {
         *(float4*)pr = make_float4(re[0], re[1], re[2], re[3]);
         *(float4*)pi = make_float4(im[0], im[1], im[2], im[3]);
@@ -294,8 +302,14 @@ __global__ __launch_bounds__(BT) void stft_frames_kernel(const pg_stft_args a) {
             }
         }
         __syncthreads();
+#if PG_STFT_ABL != 3
         if (gw.g + gw.step < gw.end) load_group(gw.g + gw.step);
+#endif
+#if PG_STFT_ABL == 2
+        const float2* Z = x;
+#else
         const float2* Z = fft_frames<1>(x, y, tw, M);
+#endif
         float* o_re = a.out + ((long)sig * 2 * M) * a.n_frames + t0;
         float* o_im = o_re + (long)M * a.n_frames;
         const bool vec = vec4 && nfr == SF;
