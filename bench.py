@@ -342,11 +342,14 @@ def run_train(a, torch, dist, world, rank, local):
         model.engine.precision = ops.precision_code("fp32")
         out["other_precisions"] = other
     if world == 1 and a.precision == "fp32" and not a.no_other_configs and (C, L, B) == (1024, 256, 64):
-        out["other_configs"] = other_configs(torch, dist, model, C, L, B)
+        out["other_configs"] = other_configs(torch, dist, model, C, L, B)      # (each leg catches its own failure)
     if world == 1 and not a.no_cpu_baseline and a.precision == "fp32":
         del trainer, model, batch
         torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline(C, L, a.cpu_threads)
+        try:
+            out["cpu_baseline"] = cpu_baseline(C, L, a.cpu_threads)
+        except Exception as e:          # noqa: BLE001
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)
     if "invalid" in out:
         sys.stdout.flush()
@@ -478,23 +481,38 @@ def measure_train(torch, model, B, C, L, seed, fuse_adam, warmup, steps):
 
 
 def other_configs(torch, dist, model, C, L, B):
-    """The other BASELINE configurations on the headline run's model (N = 1, fp32), each a few seconds."""
+    """The other BASELINE configurations on the headline run's model (N = 1, fp32), each a few seconds.  A leg that fails reports
+    its error under its own key: the others, and the headline, stand."""
     from phasegen import ops
     out = {}
-    out["dp_equivalent"] = dict(measure_train(torch, model, B, C, L, 1, False, 2, 5),
-                                note="the headline step with fuse_adam=False: what every rank of an N > 1 run executes")
-    out["ref_default"] = dict(measure_train(torch, model, 16, C, 128, 3, True, 2, 10),
-                              note="the reference's own defaults, train.py:14-15: batch 16, 1024 bins x 128 frames")
-    f = measure_fwd(torch, dist, 1, 0, model, C, L, 32, 3, 10)
-    out["fwd"] = {k: f[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "encoder_convs")}
-    out["fwd"]["roofline"] = {k: v for k, v in f["roofline"].items() if k != "by_kernel"}
-    old = model.engine.precision
-    model.engine.precision = ops.precision_code("bf16")
-    try:
-        e = measure_e2e(torch, dist, 1, 0, model, 32, 3, 10)
-    finally:
-        model.engine.precision = old
-    out["e2e"] = {k: e[k] for k in ("metric", "value", "unit", "clips_per_s", "ms_per_step", "dtype", "config", "stage_ms", "roofline")}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:          # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    def fwd():
+        f = measure_fwd(torch, dist, 1, 0, model, C, L, 32, 3, 10)
+        r = {k: f[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "encoder_convs")}
+        r["roofline"] = {k: v for k, v in f["roofline"].items() if k != "by_kernel"}
+        return r
+
+    def e2e():
+        old = model.engine.precision
+        model.engine.precision = ops.precision_code("bf16")
+        try:
+            e = measure_e2e(torch, dist, 1, 0, model, 32, 3, 10)
+        finally:
+            model.engine.precision = old
+        return {k: e[k] for k in ("metric", "value", "unit", "clips_per_s", "ms_per_step", "dtype", "config", "stage_ms", "roofline")}
+
+    leg("dp_equivalent", lambda: dict(measure_train(torch, model, B, C, L, 1, False, 2, 5),
+                                      note="the headline step with fuse_adam=False: what every rank of an N > 1 run executes"))
+    leg("ref_default", lambda: dict(measure_train(torch, model, 16, C, 128, 3, True, 2, 10),
+                                    note="the reference's own defaults, train.py:14-15: batch 16, 1024 bins x 128 frames"))
+    leg("fwd", fwd)
+    leg("e2e", e2e)
     return out
 
 
