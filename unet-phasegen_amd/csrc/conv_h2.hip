@@ -18,6 +18,9 @@ constexpr int KB = 32;                    // k per slab (two MFMA k-steps of 16)
 constexpr int H_HEAD = 32;                // zero elements the caller guarantees in front of x (PG_H_HEAD)
 constexpr int NT2 = 512;                  // threads per workgroup
 constexpr int H2_LDS = 156 * 1024;        // LDS budget of the ring of three stage groups
+#ifndef PG_H2_STAGGER
+#define PG_H2_STAGGER 0
+#endif
 #ifndef PG_H2_SPREAD
 #define PG_H2_SPREAD 1
 #endif
@@ -168,6 +171,9 @@ __global__ __launch_bounds__(NT2, 2) void conv_h2_kernel(const IgemmParams p) {
         int st = 0;
         for (int sl = sb; sl < se; sl += SPB) {
             const int st2 = st >= 1 ? st - 1 : 2;                // (st + 2) % 3
+#if PG_H2_STAGGER        /* dev knob: waves 4-7 (the SIMD partners of 0-3) start each group PG_H2_STAGGER x 64 cycles late */
+            if (wv >= 4) __builtin_amdgcn_s_sleep(PG_H2_STAGGER);
+#endif
             PG_STAMP(0)
             const int nsl = min(SPB, se - sl);
 #if PG_H2_SPREAD
