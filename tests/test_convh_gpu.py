@@ -198,6 +198,12 @@ def test_conv_fwd_h_random_geometries(geom):
     if ops.conv_fwd_h_supported(B, tuple(w.shape), Lin, s, p, tr):
         ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y)
         assert relerr(y, want) < 2e-5
+        # ... under every tile family with the stream-K split forced (partial tiles through the workspace + the fixup kernels; the
+        # 8-wave families run the three-stage ring with counted waits) and one tile per workgroup
+        for sched in (32 | 2, 64 | 2, 96 | 2, 64 | 1, 96 | 1):
+            y.fill_(float("nan"))
+            ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y, schedule=sched)
+            assert relerr(y, want) < 2e-5, sched
     else:
         with pytest.raises(RuntimeError, match="not covered"):
             ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y)
