@@ -52,7 +52,7 @@ def sample_points(rng, n, Cout, Lout):
     return pts
 
 
-@pytest.mark.parametrize("sched", [0, 1, 2, 32, 64, 96], ids=["auto", "tile-per-wg", "stream-k", "128x256", "128x512", "256x256"])
+@pytest.mark.parametrize("sched", [0, 1, 2, 32, 64, 96, 4096], ids=["auto", "tile-per-wg", "stream-k", "128x256", "128x512", "256x256", "256x256w4"])
 @pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
 def test_conv_h_layer_at_full_size(layer, sched):
     from phasegen import ops

@@ -34,13 +34,13 @@ GEOMS = [
 
 
 # schedule word: bits 0-1 work split (0 auto, 1 one tile per workgroup, 2 stream-K), bits 5-6 tile family (32: 128 x 256 on 4 waves,
-# 64: 128 x 512 and 96: 256 x 256 on 8 waves; 0: automatic)
-SCHEDS = [0, 1, 2, 32 | 1, 32 | 2, 64 | 1, 64 | 2, 96 | 1, 96 | 2]
+# 64: 128 x 512 and 96: 256 x 256 on 8 waves; 0: automatic), bit 12 (4096: 256 x 256 on 4 waves, one per SIMD -- conv_h3.hip)
+SCHEDS = [0, 1, 2, 32 | 1, 32 | 2, 64 | 1, 64 | 2, 96 | 1, 96 | 2, 4096 | 1, 4096 | 2]
 
 
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("sched", SCHEDS, ids=["auto", "tile-per-wg", "stream-k", "128x256/tile", "128x256/stream-k", "128x512/tile",
-                                               "128x512/stream-k", "256x256/tile", "256x256/stream-k"])
+                                               "128x512/stream-k", "256x256/tile", "256x256/stream-k", "256x256w4/tile", "256x256w4/stream-k"])
 def test_conv_fwd_h_vs_float64_of_the_bf16_operands(geom, sched):
     from phasegen import ops
     tr, Cin, Cout, k, s, p, Lin, B = geom
@@ -200,7 +200,7 @@ def test_conv_fwd_h_random_geometries(geom):
         assert relerr(y, want) < 2e-5
         # ... under every tile family with the stream-K split forced (partial tiles through the workspace + the fixup kernels; the
         # 8-wave families run the three-stage ring with counted waits) and one tile per workgroup
-        for sched in (32 | 2, 64 | 2, 96 | 2, 64 | 1, 96 | 1):
+        for sched in (32 | 2, 64 | 2, 96 | 2, 64 | 1, 96 | 1, 4096 | 1, 4096 | 2):
             y.fill_(float("nan"))
             ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y, schedule=sched)
             assert relerr(y, want) < 2e-5, sched

@@ -14,7 +14,7 @@ L1, L2, L3, L4 = frame_plan(L)
 geo = {"D0": (C, 2 * C, 32, L), "D1": (2 * C, 2 * C, 8, L1), "D2": (2 * C, 2 * C, 8, L2), "D3": (2 * C, 4 * C, 4, L3),
        "U3": (4 * C, 2 * C, 5, L4), "U2": (4 * C, 2 * C, 8, L3), "U1": (4 * C, 2 * C, 8, L2), "U0": (4 * C, 2 * C, 32, L1)}
 fl = bench.conv_flops(C, L, B)
-FAM = {"128x256": 32, "128x512": 64, "256x256": 96, "auto": 0, "128x256/1tile": 33, "128x512/1tile": 65, "256x256/1tile": 97}
+FAM = {"256x256w4": 4096, "256x256w4/1tile": 4097, "128x256": 32, "128x512": 64, "256x256": 96, "auto": 0, "128x256/1tile": 33, "128x512/1tile": 65, "256x256/1tile": 97}
 def once(fn, reps=5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -525,6 +525,9 @@ hipError_t launch_h(int kind, const IgemmParams& p, int grid, hipStream_t st);  
 // conv_h2.hip: the same on 8 waves, one workgroup per CU; wm = 1: tile 128 x 512, wm = 2: tile 256 x 256
 hipError_t launch_h2(int kind, int wm, const IgemmParams& p, int grid, hipStream_t st);
 hipError_t launch_h2_fixup(int kind, int wm, const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
+// conv_h3.hip: 4 waves at ONE per SIMD, wave tile 256 x 64, tile 256 x 256
+hipError_t launch_h3(int kind, const IgemmParams& p, int grid, hipStream_t st);
+hipError_t launch_h3_fixup(int kind, const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
 bool h_supported_tn(int kind, const IgemmParams& p, int tn);      // geometry covered by a bf16-resident kernel whose tile is tn columns wide
 inline bool h_supported(int kind, const IgemmParams& p) { return h_supported_tn(kind, p, 256); }
 }  // namespace pgconv

@@ -93,18 +93,20 @@ struct Knobs {
     int oversub;      // stream-K grid = up to oversub x resident workgroup slots
     int contended;    // other kernels (RCCL collectives) are expected to hold part of the chip: always take the finer split
     int no_ps;        // wgrad: 1 = never the per-sample-slab kernel (A/B, tests)
-    int hvar;         // pg_conv_fwd_h only: tile family, 0 automatic, 1 = 128 x 256 (4 waves), 2 = 128 x 512, 3 = 256 x 256 (8 waves)
+    int hvar;         // pg_conv_fwd_h only: tile family, 0 automatic, 1 = 128 x 256 (4 waves), 2 = 128 x 512, 3 = 256 x 256 (8 waves),
+                      // 4 = 256 x 256 on 4 waves at one per SIMD (conv_h3.hip; schedule bit 12)
     char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
 };
 int decode_knobs(const pg_conv_args* a, Knobs& k) {
     if (a->precision < 0 || a->precision > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv: precision must be PG_PREC_FP32, PG_PREC_BF16 or PG_PREC_BF16X3");
     const int sc = a->schedule;
-    if (sc < 0 || (sc & ~0xfff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
+    if (sc < 0 || (sc & ~0x1fff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
     k.prec = a->precision;
     k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
     k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
     k.contended = (sc >> 4) & 1;
     k.hvar = (sc >> 5) & 3;
+    if (sc & 0x1000) { if (k.hvar) return pg_fail(PG_ERR_SHAPE, "conv: schedule bit 12 excludes bits 5-6"); k.hvar = 4; }
     k.no_ps = (sc >> 7) & 1;
     k.desc = nullptr; k.desc_len = 0;
     return PG_OK;
@@ -425,11 +427,12 @@ extern "C" int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, in
 
 // ---- bf16-resident forward (conv_h.hip) ----------------------------------------------------------------------------------
 // automatic tile family of pg_conv_fwd_h (measured on MI355X at the U-Net's layer shapes, tools/convh_bench.py)
-static int h_auto_variant(int kwp, int sc, long rows, long cols) {
+static int h_auto_variant(bool tr, int kwp, int sc, long rows, long cols) {
     (void)rows; (void)cols;
-    // unit window step (every transposed conv; D1) or 32 taps per channel (D0): the wide 8-wave tile, +3 ... 7 % (U2 / U3: +5 / +3 %);
-    // stride-2 windows of short taps (D2, D3), whose window bytes double with the tile width: the 4-wave 128 x 256 tile
-    return (kwp >= 32 || sc == 1) ? 2 : 1;
+    // forward convs with 32 taps per channel (D0) or unit stride (D1): the wide 8-wave tile (D0 +3 % over the one-wave-per-SIMD tile,
+    // D1 level with it); every transposed conv and the stride-2 convs of short taps (D2, D3): 256 x 256 on 4 waves, one per SIMD
+    // (conv_h3.hip; -2 ... -8 % per layer against the best two-waves-per-SIMD family)
+    return (!tr && (kwp >= 32 || sc == 1)) ? 2 : 4;
 }
 
 static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, char* desc = nullptr, int desc_len = 0) {
@@ -469,14 +472,15 @@ static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, cha
         if (p.U <= 0) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: empty output");
     }
     // Tile family (conv_h2.hip's header has the bytes-per-FLOP arithmetic): 1 = 128 x 256 on 4 waves, two workgroups per CU;
-    // 2 = 128 x 512 and 3 = 256 x 256 on 8 waves, one workgroup per CU.  schedule bits 5-6 force one (tests, tools/convh_bench.py).
+    // 2 = 128 x 512 and 3 = 256 x 256 on 8 waves, one workgroup per CU; 4 = 256 x 256 on 4 waves, one workgroup per CU and one wave
+    // per SIMD (conv_h3.hip).  schedule bits 5-6 / bit 12 force one (tests, tools/convh_bench.py).
     const bool ok1 = pgconv::h_supported_tn(kind, p, 256), ok2 = pgconv::h_supported_tn(kind, p, 512);
     if (!ok1) return pg_fail(PG_ERR_UNSUPPORTED, "conv_fwd_h: geometry not covered by the bf16-resident kernels (use the fp32-tensor entry points)");
     if (query) return PG_OK;
     const long rows = tr ? (long)p.M * p.s : p.M, cols = (long)p.B * (tr ? p.U : p.Ly), Ktot = (long)p.Q * kwp;
-    int var = kn.hvar ? kn.hvar : h_auto_variant(kwp, tr ? 1 : p.s, rows, cols);
+    int var = kn.hvar ? kn.hvar : h_auto_variant(tr, kwp, tr ? 1 : p.s, rows, cols);
     if (var == 2 && !ok2) var = 3;
-    const int wm = var == 3 ? 2 : 1, tm = var == 3 ? 2 * RBM : RBM, tn = var == 2 ? 2 * RBN : RBN;
+    const int wm = var == 3 ? 2 : 1, tm = var >= 3 ? 2 * RBM : RBM, tn = var == 2 ? 2 * RBN : RBN;
     p.tilesM = (int)((rows + tm - 1) / tm);
     p.tilesN = (int)((cols + tn - 1) / tn);
     p.tn_stride = tn;
@@ -488,15 +492,16 @@ static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, cha
                               : pick_grid(tiles, p.nslab, p, a->workspace_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG);
     const bool split = grid != tiles && !(tiles % grid == 0);
     if (desc) {
-        snprintf(desc, (size_t)desc_len, "conv_h%s_kernel<%d, %d, %s%s>|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", var == 1 ? "" : "2",
-                 (tr && p.k == 5) ? 8 : p.k, p.s, tr ? "true" : "false", var == 1 ? "" : (var == 2 ? ", 1" : ", 2"), grid, tiles, p.nslab, (int)split, p.whole);
+        snprintf(desc, (size_t)desc_len, "conv_h%s_kernel<%d, %d, %s%s>|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", var == 1 ? "" : (var == 4 ? "3" : "2"),
+                 (tr && p.k == 5) ? 8 : p.k, p.s, tr ? "true" : "false", (var == 1 || var == 4) ? "" : (var == 2 ? ", 1" : ", 2"), grid, tiles, p.nslab, (int)split, p.whole);
         return PG_OK;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = var == 1 ? pgconv::launch_h(kind, p, grid, st) : pgconv::launch_h2(kind, wm, p, grid, st);
+    hipError_t e = var == 1 ? pgconv::launch_h(kind, p, grid, st) : var == 4 ? pgconv::launch_h3(kind, p, grid, st) : pgconv::launch_h2(kind, wm, p, grid, st);
     if (e == hipSuccess && split) {
-        const unsigned blocks = (unsigned)((tiles - p.whole) * 8);
-        if (var != 1) e = pgconv::launch_h2_fixup(kind, wm, p, grid, blocks, st);
+        const unsigned blocks = (unsigned)((tiles - p.whole) * (var == 4 ? 16 : 8));
+        if (var == 4) e = pgconv::launch_h3_fixup(kind, p, grid, blocks, st);
+        else if (var != 1) e = pgconv::launch_h2_fixup(kind, wm, p, grid, blocks, st);
         else {
             if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 4, 2, 4>), dim3(blocks), dim3(NT), 0, st, p, grid);
             else hipLaunchKernelGGL((conv_fixup_kernel<1, 4, 2, 4>), dim3(blocks), dim3(NT), 0, st, p, grid);

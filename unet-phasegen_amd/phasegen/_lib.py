@@ -17,6 +17,7 @@ OP_CONV1D_FWD, OP_CONV1D_DGRAD, OP_CONV1D_WGRAD, OP_CONVT1D_FWD, OP_CONVT1D_DGRA
 SCHED_AUTO, SCHED_TILE_PER_WG, SCHED_FORCE_STREAMK, SCHED_NO_RAW, SCHED_NO_TALL, SCHED_CONTENDED = 0, 1, 2, 4, 8, 16   # pg_conv_args.schedule bits
 SCHED_NO_PS = 128      # wgrad: keep the flat-K raw kernel (no per-sample slabs)
 SCHED_H_128x256, SCHED_H_128x512, SCHED_H_256x256 = 32, 64, 96   # pg_convh_args.schedule bits 5-6: tile family of pg_conv_fwd_h (0 = automatic)
+SCHED_H_256x256_W4 = 4096    # ... bit 12 (excludes bits 5-6): 256 x 256 on 4 waves, one per SIMD (conv_h3.hip)
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
