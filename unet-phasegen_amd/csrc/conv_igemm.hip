@@ -428,11 +428,12 @@ extern "C" int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, in
 // ---- bf16-resident forward (conv_h.hip) ----------------------------------------------------------------------------------
 // automatic tile family of pg_conv_fwd_h (measured on MI355X at the U-Net's layer shapes, tools/convh_bench.py)
 static int h_auto_variant(bool tr, int kwp, int sc, long rows, long cols) {
-    (void)rows; (void)cols;
-    // forward convs with 32 taps per channel (D0) or unit stride (D1): the wide 8-wave tile (D0 +3 % over the one-wave-per-SIMD tile,
-    // D1 level with it); every transposed conv and the stride-2 convs of short taps (D2, D3): 256 x 256 on 4 waves, one per SIMD
-    // (conv_h3.hip; -2 ... -8 % per layer against the best two-waves-per-SIMD family)
-    return (!tr && (kwp >= 32 || sc == 1)) ? 2 : 4;
+    (void)tr; (void)kwp; (void)sc; (void)rows; (void)cols;
+    // 256 x 256 on 4 waves, one per SIMD (conv_h3.hip), for every layer: inside the U-Net forward (bf16 outputs) it is level with
+    // or ahead of the best two-waves-per-SIMD family on all eight (tools/dbg/e2e_fam.py: forward 6.44 ms against 6.55 / 6.73 / 6.88
+    // with everything on 128 x 512 / 128 x 256 / 256 x 256 on 8 waves).  With an fp32 output alone (tools/convh_bench.py) the
+    // 128 x 512 tile keeps 3 % on D0; the other families stay selectable through the schedule word.
+    return 4;
 }
 
 static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, char* desc = nullptr, int desc_len = 0) {
