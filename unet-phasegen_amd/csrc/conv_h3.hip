@@ -252,11 +252,23 @@ __global__ __launch_bounds__(NT3, 1) void conv_h3_kernel(const IgemmParams p) {
             if (e < NAW) dma16s(rw, stage + 256 * (wv + 4 * e), live ? avoff[e < NAW ? e : 0] : FAR, k0 * 2);
             else if (e < NAW + NPW) dma16s(rx, stage + TA + 256 * (wv + 4 * (e - NAW)), live ? voff[e < NAW ? 0 : e - NAW] : FAR, (k0 / KWP) * p.x_pitch * 2);
         };
-        auto wait_landed = [&]() {       // all gathers done except (at most) the youngest group's
+        // Waits.  wait_first: before the first read of a segment -- everything but the youngest group (group 1) has landed.  wait_next:
+        // in front of the LAST k-step of stage group i, whose MFMA gaps carry the reads of group i + 1's first fragments -- so the
+        // next group starts on loaded registers instead of 16 exposed LDS reads behind its barrier (~250 of ~2000 + cycles per group).
+        // By then this wave has issued, of group i + 2, the gathers of slabs 0 ... SPB - 2 and the first k-step's three of the last
+        // slab: NMID younger instructions may stay in flight, everything older (group i + 1) is done.  The barrier also closes the
+        // reads of group i for every wave (its last k-step multiplies registers): group i + 3's gathers may overwrite its slot.
+        constexpr int NMID = (SPB - 1) * (NAW + NPW) + 3;
+        auto wait_first = [&]() {
+            h3_wait_vmcnt<NGRP>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto wait_next = [&]() {
 #ifdef PG_H3_ABL
             h3_wait_vmcnt<0>();
 #else
-            h3_wait_vmcnt<NGRP>();
+            h3_wait_vmcnt<NMID>();
 #endif
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -266,25 +278,25 @@ __global__ __launch_bounds__(NT3, 1) void conv_h3_kernel(const IgemmParams p) {
 #pragma unroll
             for (int e = 0; e < NAW + NPW; ++e) issue_piece(lds + hf * STG, sb + hf, e);
         __builtin_amdgcn_sched_barrier(0);
-        wait_landed();
+        wait_first();
+        H3Frag f0, f1;
+        {
+            const unsigned aa = h3_a_addr(lds, 0, r, h);
+            h3_load_b<TJ, RSD, 0>(h3_b_addr<TJ, RSD, TA>(lds, 0, h, bdw[0]), f0);
+            h3_load_b<TJ, RSD, 1>(h3_b_addr<TJ, RSD, TA>(lds, 0, h, bdw[1]), f0);
+            h3_load_a<0>(aa, f0); h3_load_a<1>(aa, f0); h3_load_a<2>(aa, f0); h3_load_a<3>(aa, f0);
+            h3_load_a<4>(aa, f0); h3_load_a<5>(aa, f0); h3_load_a<6>(aa, f0); h3_load_a<7>(aa, f0);
+            h3_lgkm0();
+            __builtin_amdgcn_sched_barrier(0);
+            h3_finish_b<TJ>(0, bsh, f0);
+            h3_finish_b<TJ>(1, bsh, f0);
+        }
         int st = 0;
         for (int sl = sb; sl < se; sl += SPB) {
-            const int st2 = st >= 1 ? st - 1 : 2;                // (st + 2) % 3
+            const int st1 = st == 2 ? 0 : st + 1, st2 = st >= 1 ? st - 1 : 2;                // (st + 1) % 3, (st + 2) % 3
             const float* const cur = lds + st * SSTG;
             float* const ring2 = lds + st2 * SSTG;
             const int s2 = sl + 2 * SPB;
-            H3Frag f0, f1;
-            {
-                const unsigned aa = h3_a_addr(cur, 0, r, h);
-                h3_load_b<TJ, RSD, 0>(h3_b_addr<TJ, RSD, TA>(cur, 0, h, bdw[0]), f0);
-                h3_load_b<TJ, RSD, 1>(h3_b_addr<TJ, RSD, TA>(cur, 0, h, bdw[1]), f0);
-                h3_load_a<0>(aa, f0); h3_load_a<1>(aa, f0); h3_load_a<2>(aa, f0); h3_load_a<3>(aa, f0);
-                h3_load_a<4>(aa, f0); h3_load_a<5>(aa, f0); h3_load_a<6>(aa, f0); h3_load_a<7>(aa, f0);
-                h3_lgkm0();
-                __builtin_amdgcn_sched_barrier(0);
-                h3_finish_b<TJ>(0, bsh, f0);
-                h3_finish_b<TJ>(1, bsh, f0);
-            }
 #pragma unroll
             for (int hf = 0; hf < SPB; ++hf) {
                 const float* const stg = cur + hf * STG;
@@ -292,11 +304,14 @@ __global__ __launch_bounds__(NT3, 1) void conv_h3_kernel(const IgemmParams p) {
                 auto issue0 = [&](int e) { if (e < 3) issue_piece(ring2 + hf * STG, s2 + hf, e); };       // first: 0 ... 2
                 h3_kstep<TJ, RSD, TA, 0, true>(f0, f1, stg, 1, r, h, bdw, bsh, acc, issue0);
                 if (hf + 1 < SPB) h3_kstep<TJ, RSD, TA, 4, true>(f1, f0, stg + STG, 0, r, h, bdw, bsh, acc, issue);
-                else h3_kstep<TJ, RSD, TA, 4, false>(f1, f0, stg, 0, r, h, bdw, bsh, acc, issue);
+                else {
+                    // (past the last group of the segment the "next" stage holds zero-filled or older slabs: read, never multiplied;
+                    // f0 is carried by the loop, so its registers stay reserved until the reads have landed)
+                    wait_next();
+                    h3_kstep<TJ, RSD, TA, 4, true>(f1, f0, lds + st1 * SSTG, 0, r, h, bdw, bsh, acc, issue);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            wait_landed();
-            st = st == 2 ? 0 : st + 1;
+            st = st1;
         }
         __syncthreads();
         if (sb == 0 && se == p.nslab) {
