@@ -18,6 +18,12 @@ for random, what in ((0, "constant operands"), (1, "random operands in [-1, 1), 
             tf, mhz = ctypes.c_double(), ctypes.c_double()
             rc = lib.mfma_peak(256 * (2 if threads == 256 else 1) * 2, threads, iters, 5, random, ctypes.byref(tf), ctypes.byref(mhz))
             print(f"register-only MFMA loop, {what}, {label}, {iters} x 4 MFMAs per wave: rc={rc} {tf.value:7.1f} TFLOP/s ({tf.value / 2516.6 * 100:4.1f} % of 2516.6), shader clock {mhz.value:6.0f} MHz", flush=True)
+lib.mfma_peak_f32.argtypes = lib.mfma_peak.argtypes
+for random, what in ((0, "constant operands"), (1, "random operands in [-1, 1), 8 register sets in rotation")):
+    for threads, label in ((256, "1 wave/SIMD"), (512, "2 waves/SIMD")):
+        tf, mhz = ctypes.c_double(), ctypes.c_double()
+        rc = lib.mfma_peak_f32(256 * (2 if threads == 256 else 1) * 2, threads, 100000, 5, random, ctypes.byref(tf), ctypes.byref(mhz))
+        print(f"register-only v_mfma_f32_32x32x2_f32 loop, {what}, {label}: rc={rc} {tf.value:7.1f} TFLOP/s ({tf.value / 157.3 * 100:4.1f} % of 157.3), shader clock {mhz.value:6.0f} MHz", flush=True)
 
 import bench
 from phasegen import ops

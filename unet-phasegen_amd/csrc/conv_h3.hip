@@ -314,6 +314,9 @@ __global__ __launch_bounds__(NT3, 1) void conv_h3_kernel(const IgemmParams p) {
             st = st1;
         }
         __syncthreads();
+        // the accumulator reads below are `asm` (h3_acc): hipcc's hazard recogniser does not see them, so the wait states an MFMA
+        // result needs before a VALU may read it (its 8 passes = 32 cycles) are spelled out -- 48 cycles, once per tile segment
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15");
         if (sb == 0 && se == p.nslab) {
             // one 32 x 32 block at a time behind scheduling fences: with all 256 accumulator registers of the wave tile in one
             // epilogue hipcc moved them to VGPRs wholesale and spilled ~200 of them -- through the MAIN loop as well
