@@ -93,6 +93,7 @@ struct Knobs {
     int oversub;      // stream-K grid = up to oversub x resident workgroup slots
     int contended;    // other kernels (RCCL collectives) are expected to hold part of the chip: always take the finer split
     int no_ps;        // wgrad: 1 = never the per-sample-slab kernel (A/B, tests)
+    int no_raw3;      // 1 = never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip; schedule bit 13: A/B, tests of the older kernels)
     int hvar;         // pg_conv_fwd_h only: tile family, 0 automatic, 1 = 128 x 256 (4 waves), 2 = 128 x 512, 3 = 256 x 256 (8 waves),
                       // 4 = 256 x 256 on 4 waves at one per SIMD (conv_h3.hip; schedule bit 12)
     char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
@@ -100,7 +101,7 @@ struct Knobs {
 int decode_knobs(const pg_conv_args* a, Knobs& k) {
     if (a->precision < 0 || a->precision > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv: precision must be PG_PREC_FP32, PG_PREC_BF16 or PG_PREC_BF16X3");
     const int sc = a->schedule;
-    if (sc < 0 || (sc & ~0x1fff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
+    if (sc < 0 || (sc & ~0x3fff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
     k.prec = a->precision;
     k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
     k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
@@ -108,6 +109,7 @@ int decode_knobs(const pg_conv_args* a, Knobs& k) {
     k.hvar = (sc >> 5) & 3;
     if (sc & 0x1000) { if (k.hvar) return pg_fail(PG_ERR_SHAPE, "conv: schedule bit 12 excludes bits 5-6"); k.hvar = 4; }
     k.no_ps = (sc >> 7) & 1;
+    k.no_raw3 = (sc >> 13) & 1;
     k.desc = nullptr; k.desc_len = 0;
     return PG_OK;
 }
@@ -190,7 +192,11 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     const bool tall = kind != KIND_G && kn.no_raw == 0 && kn.no_tall == 0 && (cols_tall * 100 <= cols_wide * 97 || !raw) &&
                       raw_supported(kind, p, kn, RBN / 2);
     if (tall) raw = true;
-    const int bm = tall ? 2 * RBM : (raw ? RBM : BM);
+    // fp32 F / T problems the one-wave-per-SIMD kernels cover (conv_raw3.hip: 256 x 256 tile) take them, unless 256-row tiles
+    // would compute over 3 % more rows than 128-row ones
+    const bool r3 = raw && !tall && kind != KIND_G && kn.prec == 0 && !kn.no_raw3 && pgconv::raw3_covers(kind, p) &&
+                    (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103;
+    const int bm = (tall || r3) ? 2 * RBM : (raw ? RBM : BM);
     int bn = tall ? RBN / 2 : (raw ? RBN : BN);
     const bool k5 = raw && p.k == 5 && p.s == 2;
     if (k5 && kind == KIND_G) bn = (RBN / 5) * 5;               // wgrad: a column tile is 51 whole channels x 5 taps = 255 columns (+ 1 idle)
@@ -208,24 +214,28 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     p.nslab = (int)((Ktot + BK - 1) / BK);
     const long tiles = (long)p.tilesM * p.tilesN;
     if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0 || cols + bn >= 0x7fffffffL) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");   // the fixup launches 8 workgroups per tile
-    const int grid = pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended);
+    const int grid = r3 ? pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG)
+                        : pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended);
     // ranges made of whole tiles (grid == tiles, or a grid that divides the tile count) leave nothing for the fixup
     const bool split = grid != tiles && !(tiles % grid == 0);
     if (kn.desc) {      // the kernel this call would launch, named as rocprofv3 names it (profiles/*_kernel_stats.csv)
         const bool spec = (p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || (p.k == 5 && p.s == 2);
         char name[96];
         if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_%s_kernel<%d, %d, %d>", p.g_ps ? "ps" : "raw", p.k, p.s, kn.prec);
+        else if (r3) snprintf(name, sizeof name, "conv_raw3_kernel<%d, %d, %s>", p.k, p.s, kind == KIND_T ? "true" : "false");
         else if (raw) snprintf(name, sizeof name, "conv_raw_kernel<%d, %d, %s, %d, %d>", p.k, p.s, kind == KIND_T ? "true" : "false", kn.prec, tall ? 1 : 2);
         else snprintf(name, sizeof name, "conv_%c_kernel<%d, %d, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), spec ? p.k : 0, spec ? p.s : 0, kn.prec);
         snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", name, grid, tiles, p.nslab, (int)split, p.whole);
         return PG_OK;
     }
     hipError_t e;
-    if (raw && kind == KIND_G) e = pgconv::launch_raw_g(p, grid, st, kn.prec);
+    if (r3) e = pgconv::launch_raw3(kind, p, grid, st);
+    else if (raw && kind == KIND_G) e = pgconv::launch_raw_g(p, grid, st, kn.prec);
     else if (tall) e = pgconv::launch_raw_ft_tall(kind, p, grid, st, kn.prec);
     else if (raw) e = pgconv::launch_raw_ft(kind, p, grid, st, kn.prec);
     else e = pgconv::launch_im2col(kind, p, grid, st, kn.prec);
-    if (e == hipSuccess && split) {
+    if (e == hipSuccess && split && r3) e = pgconv::launch_raw3_fixup(kind, p, grid, (unsigned)((tiles - p.whole) * 16), st);
+    else if (e == hipSuccess && split) {
         if (tall) {
             if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
             else if (p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
