@@ -24,6 +24,11 @@ for random, what in ((0, "constant operands"), (1, "random operands in [-1, 1), 
         tf, mhz = ctypes.c_double(), ctypes.c_double()
         rc = lib.mfma_peak_f32(256 * (2 if threads == 256 else 1) * 2, threads, 100000, 5, random, ctypes.byref(tf), ctypes.byref(mhz))
         print(f"register-only v_mfma_f32_32x32x2_f32 loop, {what}, {label}: rc={rc} {tf.value:7.1f} TFLOP/s ({tf.value / 157.3 * 100:4.1f} % of 157.3), shader clock {mhz.value:6.0f} MHz", flush=True)
+lib.mfma_peak_f32_16.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_double)] * 2
+for random in (0, 1):
+    tf, mhz = ctypes.c_double(), ctypes.c_double()
+    rc = lib.mfma_peak_f32_16(256, 20000, 5, random, ctypes.byref(tf), ctypes.byref(mhz))
+    print(f"register-only v_mfma_f32_32x32x2_f32 loop, 16 accumulators (256 registers, AGPRs), 1 wave/SIMD, {'random' if random else 'constant'} operands: rc={rc} {tf.value:7.1f} TFLOP/s ({tf.value / 157.3 * 100:4.1f} % of 157.3), shader clock {mhz.value:6.0f} MHz", flush=True)
 
 import bench
 from phasegen import ops

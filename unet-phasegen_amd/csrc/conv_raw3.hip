@@ -112,9 +112,16 @@ __device__ __forceinline__ void r3_half(const R3Frag& cur, R3Frag& nxt, const fl
                                                                          cur.b[(C) & 1][(C) >> 4], acc.c[((C) >> 1) & 7][(C) & 1], 0, 0, 0); \
     WORK;
 #define R3_ROW(C0, W0, W1, W2, W3) R3_CHUNK(C0, W0) R3_CHUNK(C0 + 1, W1) R3_CHUNK(C0 + 2, W2) R3_CHUNK(C0 + 3, W3)
+#if defined(PG_R3_ABL) && (PG_R3_ABL == 4 || PG_R3_ABL == 5 || PG_R3_ABL == 7)
+    (void)a0; (void)a1; (void)b0; (void)b1;
+    R3_ROW(0, (void)0, (void)0, (void)0, (void)0)
+    R3_ROW(4, (void)0, (void)0, (void)0, (void)0)
+    R3_ROW(8, (void)0, (void)0, (void)0, (void)0)
+#else
     R3_ROW(0, (r3_load_b<0, 0>(b0, nxt)), (r3_load_b<0, 1>(b0, nxt)), (r3_load_b<1, 0>(b1, nxt)), (r3_load_b<1, 1>(b1, nxt)))
     R3_ROW(4, (r3_load_a<PM, 0>(a0, a1, nxt)), (r3_load_a<PM, 1>(a0, a1, nxt)), (r3_load_a<PM, 2>(a0, a1, nxt)), (r3_load_a<PM, 3>(a0, a1, nxt)))
     R3_ROW(8, (r3_load_a<PM, 4>(a0, a1, nxt)), (r3_load_a<PM, 5>(a0, a1, nxt)), (r3_load_a<PM, 6>(a0, a1, nxt)), (r3_load_a<PM, 7>(a0, a1, nxt)))
+#endif
     R3_ROW(12, issue(E0 + 0), (void)0, (void)0, (void)0)
     R3_ROW(16, issue(E0 + 1), (void)0, (void)0, (void)0)
     R3_ROW(20, issue(E0 + 2), (void)0, (void)0, (void)0)
@@ -127,9 +134,15 @@ __device__ __forceinline__ void r3_half(const R3Frag& cur, R3Frag& nxt, const fl
     R3_ROW(48, issue(E0 + 9), (void)0, (void)0, (void)0)
     R3_ROW(52, issue(E0 + 10), (void)0, (void)0, (void)0)
     R3_ROW(56, issue(E0 + 11), (void)0, (void)0, (void)0)
+#if defined(PG_R3_ABL) && PG_R3_ABL >= 4
+    R3_CHUNK(60, (void)0)
+    R3_CHUNK(61, (void)0)
+    nxt = cur;
+#else
     R3_CHUNK(60, r3_lgkm0())
     __builtin_amdgcn_sched_barrier(0);
     R3_CHUNK(61, r3_finish_b<DESC>(nxt, slope))
+#endif
     R3_CHUNK(62, (void)0)
     R3_CHUNK(63, (void)0)
     __builtin_amdgcn_sched_barrier(0);
@@ -172,6 +185,9 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wv;
     const int r = lane & 31, h = lane >> 5;
+#if PG_ABL == 8   /* dev-only: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (tools/clock_probe.py) */
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int Lcol = TKIND ? p.U : p.Ly;              // columns (output positions) per sample
     const int Ktot = p.Q * KWP, Mrows = TKIND ? p.M * S : p.M;
     const rsrc_t rw = make_rsrc(p.w, p.w_bytes), rx = make_rsrc(p.x, p.x_bytes);
@@ -239,8 +255,9 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
         // gather number e of slab `slab` into its stage: e < AE16 the weight rows, then window piece (e - AE16) % NPC of channel
         // (e - AE16) / NPC.  A slab past this workgroup's K range is gathered from out-of-range offsets: zeros, no traffic.
         auto issue_piece = [&](float* stage, int slab, int e) {
-#ifdef PG_R3_ABL          // dev ablation (wrong results): 1 = no gathers inside the loop, 2 = no window gathers, 3 = no weight gathers
-            if (slab >= sb + 2 && (PG_R3_ABL == 1 || (PG_R3_ABL == 2 && e >= AE16) || (PG_R3_ABL == 3 && e < AE16))) return;
+#ifdef PG_R3_ABL          // dev ablation (wrong results): 1 = no gathers inside the loop, 2 = no window gathers, 3 = no weight gathers,
+                          // 4 = 1 + no LDS reads in the loop, 5 = 4 + no barrier, 6 = 1 + no activation VALU
+            if (slab >= sb + 2 && (PG_R3_ABL == 1 || PG_R3_ABL >= 4 || (PG_R3_ABL == 2 && e >= AE16) || (PG_R3_ABL == 3 && e < AE16))) return;
 #endif
             const bool live = slab < se;
             const int k0 = slab * BK;
@@ -279,7 +296,9 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
 #else
             r3_wait_vmcnt<ND0>();
 #endif
+#if !(defined(PG_R3_ABL) && PG_R3_ABL == 5)
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
         };
 #pragma unroll
@@ -317,6 +336,11 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
         __syncthreads();
         // the accumulator reads below are `asm`: the wait states an MFMA result needs before a VALU may read it, spelled out
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+#if defined(PG_R3_ABL) && PG_R3_ABL == 7      /* 4 + no epilogue: one store per wave keeps the loop alive */
+        if (p.nslab < 0) store_partial_r3(p.ws, g, slot, acc, tid);
+        else if (lane == 0) p.y[wv] = r3_acc(acc.c[0][0][0]);
+        pos += se - sb; slot = 1; continue;
+#endif
         if (sb == 0 && se == p.nslab) {
 #define R3_EPI(I, J)                                                                                              \
     {   AccT<1, 1> blk;                                                                                          \
@@ -334,6 +358,13 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
         pos += se - sb;
         slot = 1;
     }
+#if PG_ABL == 8
+    if (tid == 0 && p.ws && blockIdx.x == gridDim.x / 2) {
+        unsigned long long* d = (unsigned long long*)p.ws;
+        d[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        d[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
 }
 
 // fixup of the stream-K split: one workgroup per (split tile, 32 x 32 block of the wave tile: 16 of them).
