@@ -42,18 +42,24 @@ GEOMS = [
     # frame counts at which the wgrad takes the per-sample-slab kernel (padding a sample to whole 16-frame slabs costs <= 7 %):
     # 61 and 30 frames of dy / x for the stride-2 families, several samples, ragged channel counts
     (False, 40, 70, 8, 2, 1, 126, 3), (False, 36, 72, 4, 2, 1, 61, 5), (True, 72, 40, 8, 2, 1, 61, 3), (False, 24, 136, 8, 1, 2, 33, 4),
+    # sized for the one-wave-per-SIMD fp32 kernels (conv_raw3.hip: 256 x 256 tiles; rows just under a multiple of 256, more than one
+    # column tile, several samples per tile): every (k, s) pair and form they cover
+    (False, 32, 250, 8, 2, 1, 130, 5), (True, 48, 120, 8, 2, 1, 70, 4), (True, 64, 128, 32, 2, 16, 65, 3), (False, 16, 250, 32, 2, 16, 200, 3),
+    (True, 32, 250, 8, 1, 2, 100, 3), (False, 32, 500, 4, 2, 1, 160, 4), (False, 48, 230, 8, 1, 2, 90, 4),
 ]
 
 
-@pytest.fixture(params=[1, 2, 5, 6, 10, 128 | 2], ids=["raw/tile-per-wg", "raw/stream-k", "im2col/tile-per-wg", "im2col/stream-k", "raw-wide-only/stream-k",
-                                                      "flat-K-wgrad/stream-k"])
+@pytest.fixture(params=[1, 2, 5, 6, 10, 128 | 2, 0x2000 | 1, 0x2000 | 2],
+                ids=["raw/tile-per-wg", "raw/stream-k", "im2col/tile-per-wg", "im2col/stream-k", "raw-wide-only/stream-k",
+                     "flat-K-wgrad/stream-k", "raw-2-waves-per-simd/tile-per-wg", "raw-2-waves-per-simd/stream-k"])
 def schedule(request):
     """Run the conv tests under both work decompositions (one whole tile per workgroup; the persistent stream-K split
     with partial tiles through the workspace + fixup kernel, which the library otherwise only picks for tile counts
     that quantise badly over the CUs) and with the raw-window F/T kernels enabled or disabled (bit 2), so the im2col
     kernels they normally replace stay covered; bit 3 keeps the small problems of this file on the wide 128 x 256 raw tile
     (they otherwise take the tall 256 x 128 one), so both tile shapes see every geometry; bit 7 keeps the wgrad on the flat-K kernel
-    where it would take the per-sample-slab one."""
+    where it would take the per-sample-slab one; bit 13 keeps the fp32 F / T problems that conv_raw3.hip covers on the older
+    two-waves-per-SIMD raw kernels."""
     from phasegen import ops
     ops.set_conv_schedule(request.param)
     yield request.param

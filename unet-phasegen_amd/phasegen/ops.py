@@ -201,17 +201,18 @@ def current_schedule():
 def set_conv_schedule(mode):
     """This thread's default schedule bits (test hook).  Bits 0-1: 0 automatic, 1 one tile per workgroup, 2 force the stream-K
     split; bit 2 (value 4): im2col kernels instead of the raw-window ones; bit 3 (value 8): never the tall 256 x 128 raw tile;
-    bit 7 (value 128): the wgrad keeps the flat-K raw kernel where it would take the per-sample-slab one."""
-    if mode < 0 or mode > 255 or (mode & 3) == 3 or (mode & 0x70):
+    bit 7 (value 128): the wgrad keeps the flat-K raw kernel where it would take the per-sample-slab one; bit 13 (value 0x2000):
+    never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip), i.e. the two-waves-per-SIMD raw kernels everywhere."""
+    if mode < 0 or (mode & ~0x20ff) or (mode & 3) == 3 or (mode & 0x70):
         raise ValueError("conv schedule: bad mode")
-    _tls.schedule = (_tls.schedule & ~0xff) | mode
+    _tls.schedule = (_tls.schedule & 0xf00) | mode
 
 
 def set_conv_oversubscribe(factor):
     """Stream-K grid = factor x resident workgroup slots (1..8).  Use > 1 when other kernels (RCCL collectives) share the chip."""
     if not 1 <= factor <= 8:
         raise ValueError("conv oversubscribe: factor must be 1..8")
-    _tls.schedule = (_tls.schedule & 0xff) | (factor << 8)
+    _tls.schedule = (_tls.schedule & ~0xf00) | (factor << 8)
 
 
 def set_stft_mode(single_frame):
