@@ -21,7 +21,7 @@ LAYERS = [("D0", False, C, 2 * C, 32, 2, 16, 256, 0), ("D1", False, 2 * C, 2 * C
           ("U1", True, 4 * C, 2 * C, 8, 1, 2, 126, 2), ("U0", True, 4 * C, 2 * C, 32, 2, 16, 129, 2)]
 
 
-@pytest.fixture(params=[0, 1, 6, 0x2000], ids=["auto", "tile-per-wg", "im2col+stream-k", "raw-2-waves-per-simd"])
+@pytest.fixture(params=[0, 1, 6, 0x2000, 0x4000], ids=["auto", "tile-per-wg", "im2col+stream-k", "raw-2-waves-per-simd", "raw-1-wave-per-simd-everywhere"])
 def schedule(request):
     from phasegen import ops
     ops.set_conv_schedule(request.param)

@@ -49,9 +49,10 @@ GEOMS = [
 ]
 
 
-@pytest.fixture(params=[1, 2, 5, 6, 10, 128 | 2, 0x2000 | 1, 0x2000 | 2],
+@pytest.fixture(params=[1, 2, 5, 6, 10, 128 | 2, 0x2000 | 1, 0x2000 | 2, 0x4000 | 1, 0x4000 | 2],
                 ids=["raw/tile-per-wg", "raw/stream-k", "im2col/tile-per-wg", "im2col/stream-k", "raw-wide-only/stream-k",
-                     "flat-K-wgrad/stream-k", "raw-2-waves-per-simd/tile-per-wg", "raw-2-waves-per-simd/stream-k"])
+                     "flat-K-wgrad/stream-k", "raw-2-waves-per-simd/tile-per-wg", "raw-2-waves-per-simd/stream-k",
+                     "raw-1-wave-per-simd-everywhere/tile-per-wg", "raw-1-wave-per-simd-everywhere/stream-k"])
 def schedule(request):
     """Run the conv tests under both work decompositions (one whole tile per workgroup; the persistent stream-K split
     with partial tiles through the workspace + fixup kernel, which the library otherwise only picks for tile counts
@@ -59,7 +60,7 @@ def schedule(request):
     kernels they normally replace stay covered; bit 3 keeps the small problems of this file on the wide 128 x 256 raw tile
     (they otherwise take the tall 256 x 128 one), so both tile shapes see every geometry; bit 7 keeps the wgrad on the flat-K kernel
     where it would take the per-sample-slab one; bit 13 keeps the fp32 F / T problems that conv_raw3.hip covers on the older
-    two-waves-per-SIMD raw kernels."""
+    two-waves-per-SIMD raw kernels, bit 14 puts every problem they cover on them (the F form of k = 32 is otherwise left out)."""
     from phasegen import ops
     ops.set_conv_schedule(request.param)
     yield request.param

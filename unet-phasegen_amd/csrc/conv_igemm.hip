@@ -94,6 +94,7 @@ struct Knobs {
     int contended;    // other kernels (RCCL collectives) are expected to hold part of the chip: always take the finer split
     int no_ps;        // wgrad: 1 = never the per-sample-slab kernel (A/B, tests)
     int no_raw3;      // 1 = never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip; schedule bit 13: A/B, tests of the older kernels)
+    int all_raw3;     // 1 = the one-wave-per-SIMD kernels wherever they cover the problem (bit 14), also where auto prefers the older ones
     int hvar;         // pg_conv_fwd_h only: tile family, 0 automatic, 1 = 128 x 256 (4 waves), 2 = 128 x 512, 3 = 256 x 256 (8 waves),
                       // 4 = 256 x 256 on 4 waves at one per SIMD (conv_h3.hip; schedule bit 12)
     char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
@@ -101,7 +102,7 @@ struct Knobs {
 int decode_knobs(const pg_conv_args* a, Knobs& k) {
     if (a->precision < 0 || a->precision > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv: precision must be PG_PREC_FP32, PG_PREC_BF16 or PG_PREC_BF16X3");
     const int sc = a->schedule;
-    if (sc < 0 || (sc & ~0x3fff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
+    if (sc < 0 || (sc & ~0x7fff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
     k.prec = a->precision;
     k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
     k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
@@ -110,6 +111,8 @@ int decode_knobs(const pg_conv_args* a, Knobs& k) {
     if (sc & 0x1000) { if (k.hvar) return pg_fail(PG_ERR_SHAPE, "conv: schedule bit 12 excludes bits 5-6"); k.hvar = 4; }
     k.no_ps = (sc >> 7) & 1;
     k.no_raw3 = (sc >> 13) & 1;
+    k.all_raw3 = (sc >> 14) & 1;
+    if (k.no_raw3 && k.all_raw3) return pg_fail(PG_ERR_SHAPE, "conv: schedule bits 13 and 14 exclude each other");
     k.desc = nullptr; k.desc_len = 0;
     return PG_OK;
 }
@@ -194,8 +197,11 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     if (tall) raw = true;
     // fp32 F / T problems the one-wave-per-SIMD kernels cover (conv_raw3.hip: 256 x 256 tile) take them, unless 256-row tiles
     // would compute over 3 % more rows than 128-row ones
+    // Not (by default) the F form of k = 32: its weight tile gathers 64-byte row segments (16 rows per instruction, against 8 whole
+    // 128-byte lines in the phase-major T image), which costs the one-wave kernel 2.5 % where the T form pays 0.9 %: measured level
+    // with the 128 x 256 kernel or 1 % behind (U0 dgrad 31.4 vs 31.1 ms, D0 forward 7.9 vs 7.8).
     const bool r3 = raw && !tall && kind != KIND_G && kn.prec == 0 && !kn.no_raw3 && pgconv::raw3_covers(kind, p) &&
-                    (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103;
+                    (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103 && (kn.all_raw3 || !(kind == KIND_F && p.k == 32));
     const int bm = (tall || r3) ? 2 * RBM : (raw ? RBM : BM);
     int bn = tall ? RBN / 2 : (raw ? RBN : BN);
     const bool k5 = raw && p.k == 5 && p.s == 2;

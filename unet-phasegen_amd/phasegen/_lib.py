@@ -17,6 +17,7 @@ OP_CONV1D_FWD, OP_CONV1D_DGRAD, OP_CONV1D_WGRAD, OP_CONVT1D_FWD, OP_CONVT1D_DGRA
 SCHED_AUTO, SCHED_TILE_PER_WG, SCHED_FORCE_STREAMK, SCHED_NO_RAW, SCHED_NO_TALL, SCHED_CONTENDED = 0, 1, 2, 4, 8, 16   # pg_conv_args.schedule bits
 SCHED_NO_PS = 128      # wgrad: keep the flat-K raw kernel (no per-sample slabs)
 SCHED_NO_RAW3 = 0x2000  # fp32 F / T: never the one-wave-per-SIMD kernels (conv_raw3.hip)
+SCHED_ALL_RAW3 = 0x4000  # ... those kernels wherever they cover the problem (also the F form of k = 32, which auto leaves on the older ones)
 SCHED_H_128x256, SCHED_H_128x512, SCHED_H_256x256 = 32, 64, 96   # pg_convh_args.schedule bits 5-6: tile family of pg_conv_fwd_h (0 = automatic)
 SCHED_H_256x256_W4 = 4096    # ... bit 12 (excludes bits 5-6): 256 x 256 on 4 waves, one per SIMD (conv_h3.hip)
 

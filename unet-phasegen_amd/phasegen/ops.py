@@ -202,8 +202,9 @@ def set_conv_schedule(mode):
     """This thread's default schedule bits (test hook).  Bits 0-1: 0 automatic, 1 one tile per workgroup, 2 force the stream-K
     split; bit 2 (value 4): im2col kernels instead of the raw-window ones; bit 3 (value 8): never the tall 256 x 128 raw tile;
     bit 7 (value 128): the wgrad keeps the flat-K raw kernel where it would take the per-sample-slab one; bit 13 (value 0x2000):
-    never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip), i.e. the two-waves-per-SIMD raw kernels everywhere."""
-    if mode < 0 or (mode & ~0x20ff) or (mode & 3) == 3 or (mode & 0x70):
+    never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip), i.e. the two-waves-per-SIMD raw kernels everywhere; bit 14 (0x4000):
+    those kernels wherever they cover the problem, also where the automatic choice keeps the older ones (F form of k = 32)."""
+    if mode < 0 or (mode & ~0x60ff) or (mode & 3) == 3 or (mode & 0x70) or (mode & 0x6000) == 0x6000:
         raise ValueError("conv schedule: bad mode")
     _tls.schedule = (_tls.schedule & 0xf00) | mode
 
