@@ -532,6 +532,9 @@ hipError_t launch_h3_fixup(int kind, const IgemmParams& p, int grid, unsigned bl
 bool raw3_covers(int kind, const IgemmParams& p);               // (k, s) pair and whole-slab K; the window-length bound is raw_supported's
 hipError_t launch_raw3(int kind, const IgemmParams& p, int grid, hipStream_t st);
 hipError_t launch_raw3_fixup(int kind, const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
+// conv_g3.hip: fp32 wgrad on 4 waves at ONE per SIMD, tile 256 x 256; mode 1 = padded per-sample slabs, 2 = leftover slabs
+hipError_t launch_g3(const IgemmParams& p, int mode, int grid, hipStream_t st);
+hipError_t launch_g3_fixup(const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
 bool h_supported_tn(int kind, const IgemmParams& p, int tn);      // geometry covered by a bf16-resident kernel whose tile is tn columns wide
 inline bool h_supported(int kind, const IgemmParams& p) { return h_supported_tn(kind, p, 256); }
 }  // namespace pgconv

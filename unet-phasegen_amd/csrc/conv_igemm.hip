@@ -195,6 +195,20 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     const bool tall = kind != KIND_G && kn.no_raw == 0 && kn.no_tall == 0 && (cols_tall * 100 <= cols_wide * 97 || !raw) &&
                       raw_supported(kind, p, kn, RBN / 2);
     if (tall) raw = true;
+    // fp32 wgrad on one wave per SIMD (conv_g3.hip: 256 x 256 tiles, slabs that never straddle samples): mode 1 pads every sample to
+    // whole 16-frame slabs (as the per-sample-slab kernel below: where that costs <= 7 % of MFMA work), mode 2 (samples of 16 cf + rem
+    // frames with rem <= 2, batch a multiple of 16: the k = 32 layers at 129 frames) gathers the rem last frames of 16 samples
+    // element-wise instead -- no padded work.  OPT-IN (schedule bit 14) only: measured 0.73-0.78 of the pipe against 0.82-0.86 for the
+    // two-waves-per-SIMD kernels -- its fragment fix-ups (activations, padding, range checks) and the wave-uniform branches around
+    // them sit in the MFMA gaps but still cost issue slots, and the fused Adam epilogue is exposed at one workgroup per CU
+    // (DESIGN.md section 4.1b).
+    int g3 = 0;
+    if (raw && kind == KIND_G && kn.prec == 0 && kn.all_raw3 && !kn.no_ps && (p.k == 32 || p.k == 8 || p.k == 4) &&
+        (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103) {
+        const long cps = (p.LP + 15) / 16, rem = p.LP % 16;
+        if (rem && rem <= 2 && p.B % 16 == 0 && (cps * 16 - p.LP) * 100 > 2L * p.LP) { g3 = 2; Ktot = (long)p.B * p.LP; }
+        else if ((cps * 16 - p.LP) * 100 <= 7L * p.LP) { g3 = 1; Ktot = (long)p.B * cps * 16; }
+    }
     // fp32 F / T problems the one-wave-per-SIMD kernels cover (conv_raw3.hip: 256 x 256 tile) take them, unless 256-row tiles
     // would compute over 3 % more rows than 128-row ones
     // Not (by default) the F form of k = 32: its weight tile gathers 64-byte row segments (16 rows per instruction, against 8 whole
@@ -202,12 +216,12 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     // with the 128 x 256 kernel or 1 % behind (U0 dgrad 31.4 vs 31.1 ms, D0 forward 7.9 vs 7.8).
     const bool r3 = raw && !tall && kind != KIND_G && kn.prec == 0 && !kn.no_raw3 && pgconv::raw3_covers(kind, p) &&
                     (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103 && (kn.all_raw3 || !(kind == KIND_F && p.k == 32));
-    const int bm = (tall || r3) ? 2 * RBM : (raw ? RBM : BM);
+    const int bm = (tall || r3 || g3) ? 2 * RBM : (raw ? RBM : BM);
     int bn = tall ? RBN / 2 : (raw ? RBN : BN);
     const bool k5 = raw && p.k == 5 && p.s == 2;
     if (k5 && kind == KIND_G) bn = (RBN / 5) * 5;               // wgrad: a column tile is 51 whole channels x 5 taps = 255 columns (+ 1 idle)
     p.g_ps = 0;
-    if (raw && kind == KIND_G && p.k != 32) {
+    if (raw && kind == KIND_G && p.k != 32 && !g3) {
         // short samples: slabs of 16 frames of ONE sample (conv_g_ps_kernel) where padding every sample to whole slabs costs <= 7 %
         // of MFMA work (30 frames: 6.7 %, 61: 4.9 %, 126: 1.6 %, 256: none; 129 would cost 11.6 % and keeps the flat K axis)
         const long cps = (p.LP + 15) / 16;
@@ -220,14 +234,15 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     p.nslab = (int)((Ktot + BK - 1) / BK);
     const long tiles = (long)p.tilesM * p.tilesN;
     if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0 || cols + bn >= 0x7fffffffL) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");   // the fixup launches 8 workgroups per tile
-    const int grid = r3 ? pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG)
+    const int grid = (r3 || g3) ? pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG)
                         : pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended);
     // ranges made of whole tiles (grid == tiles, or a grid that divides the tile count) leave nothing for the fixup
     const bool split = grid != tiles && !(tiles % grid == 0);
     if (kn.desc) {      // the kernel this call would launch, named as rocprofv3 names it (profiles/*_kernel_stats.csv)
         const bool spec = (p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || (p.k == 5 && p.s == 2);
         char name[96];
-        if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_%s_kernel<%d, %d, %d>", p.g_ps ? "ps" : "raw", p.k, p.s, kn.prec);
+        if (g3) snprintf(name, sizeof name, "conv_g3_kernel<%d, %d, %s>", p.k, p.s, g3 == 1 ? "true" : "false");
+        else if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_%s_kernel<%d, %d, %d>", p.g_ps ? "ps" : "raw", p.k, p.s, kn.prec);
         else if (r3) snprintf(name, sizeof name, "conv_raw3_kernel<%d, %d, %s>", p.k, p.s, kind == KIND_T ? "true" : "false");
         else if (raw) snprintf(name, sizeof name, "conv_raw_kernel<%d, %d, %s, %d, %d>", p.k, p.s, kind == KIND_T ? "true" : "false", kn.prec, tall ? 1 : 2);
         else snprintf(name, sizeof name, "conv_%c_kernel<%d, %d, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), spec ? p.k : 0, spec ? p.s : 0, kn.prec);
@@ -235,12 +250,14 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
         return PG_OK;
     }
     hipError_t e;
-    if (r3) e = pgconv::launch_raw3(kind, p, grid, st);
+    if (g3) e = pgconv::launch_g3(p, g3, grid, st);
+    else if (r3) e = pgconv::launch_raw3(kind, p, grid, st);
     else if (raw && kind == KIND_G) e = pgconv::launch_raw_g(p, grid, st, kn.prec);
     else if (tall) e = pgconv::launch_raw_ft_tall(kind, p, grid, st, kn.prec);
     else if (raw) e = pgconv::launch_raw_ft(kind, p, grid, st, kn.prec);
     else e = pgconv::launch_im2col(kind, p, grid, st, kn.prec);
-    if (e == hipSuccess && split && r3) e = pgconv::launch_raw3_fixup(kind, p, grid, (unsigned)((tiles - p.whole) * 16), st);
+    if (e == hipSuccess && split && g3) e = pgconv::launch_g3_fixup(p, grid, (unsigned)((tiles - p.whole) * 16), st);
+    else if (e == hipSuccess && split && r3) e = pgconv::launch_raw3_fixup(kind, p, grid, (unsigned)((tiles - p.whole) * 16), st);
     else if (e == hipSuccess && split) {
         if (tall) {
             if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
