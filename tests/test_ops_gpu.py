@@ -382,6 +382,59 @@ def test_conv_random_geometries_vs_torch(geom):
     assert relerr(y, yr) < TOL and relerr(dx, xr.grad) < TOL and relerr(dw, wr.grad) < TOL
 
 
+def _random_geoms_one_wave(n, seed):
+    """Seeded sweep sized for the one-wave-per-SIMD fp32 kernels (conv_raw3.hip, and conv_g3.hip under schedule bit 14): GEMM rows
+    just under a multiple of 256 on the side that matters, channel counts that give whole 16-deep slabs, frame counts from less than a
+    column tile to several samples per tile, every (k, stride) pair they cover, paddings up to k - 1."""
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        tr = bool(rs.randint(2))
+        k, s = [(32, 2), (8, 1), (8, 2), (4, 2)][rs.randint(4)]
+        p = int(rs.randint(0, k))
+        big, small = int(rs.choice([200, 236, 250, 256, 470, 500])), int(rs.choice([8, 16, 24, 32, 48]))
+        # conv: rows of fwd = Cout, of dgrad (T form) = Cin * s; convT: rows of fwd (T form) = Cout * s, of dgrad = Cin
+        Cin, Cout = (small, big) if rs.randint(2) else (big // (s if not tr else 1), small * 4)
+        Lin, B = int(rs.choice([17, 30, 33, 61, 64, 100, 129])), int(rs.choice([1, 2, 3, 5, 16]))
+        Lout = (Lin - 1) * s - 2 * p + k if tr else (Lin + 2 * p - k) // s + 1
+        if Lout < 1 or (not tr and Lin + 2 * p < k) or B * max(Lin, Lout) * max(Cin, Cout) > 3_000_000:
+            continue
+        out.append((tr, Cin, Cout, k, s, p, Lin, B))
+    return out
+
+
+@pytest.mark.parametrize("sched", [0, 0x4000 | 2], ids=["auto", "one-wave-everywhere/stream-k"])
+@pytest.mark.parametrize("geom", _random_geoms_one_wave(32, 20261005), ids=lambda g: f"{'T' if g[0] else 'C'}{g[1]}-{g[2]}-k{g[3]}s{g[4]}p{g[5]}-L{g[6]}-B{g[7]}")
+def test_conv_random_geometries_one_wave_kernels(geom, sched):
+    """forward / dgrad / wgrad (with an input activation on the window operand and the fused dgrad epilogue) of 32 seeded random
+    geometries sized for the one-wave-per-SIMD kernels, under the automatic schedule and with those kernels forced wherever they
+    cover the problem, against fp32 torch on the CPU."""
+    from phasegen import ops
+    tr, Cin, Cout, k, s, p, Lin, B = geom
+    x = rnd(21, B, Cin, Lin)
+    w = rnd(22, *((Cin, Cout, k) if tr else (Cout, Cin, k))) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xa = act_cpu(xr, 1)
+    xa.retain_grad()
+    yr = F.conv_transpose1d(xa, wr, stride=s, padding=p) if tr else F.conv1d(xa, wr, stride=s, padding=p)
+    dy = rnd(23, *yr.shape)
+    yr.backward(dy)
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    ops.set_conv_schedule(sched)
+    try:
+        y = torch.full(yr.shape, float("nan"), device="cuda")
+        ops.conv_fwd(xd, wd, y, s, p, x_act=1, transposed=tr)
+        dx = torch.full(x.shape, float("nan"), device="cuda")
+        add = rnd(24, *x.shape)
+        ops.conv_dgrad(dyd, wd, dx, s, p, transposed=tr, add=add.cuda(), ref=xd, mask=1)
+        dw = torch.full(w.shape, float("nan"), device="cuda")
+        ops.conv_wgrad(xd, dyd, dw, s, p, x_act=1, transposed=tr)
+    finally:
+        ops.set_conv_schedule(0)
+    want_dx = (xa.grad + add) * torch.where(x > 0, torch.ones_like(x), torch.full_like(x, 0.2))
+    assert relerr(y, yr) < TOL and relerr(dx, want_dx) < TOL and relerr(dw, wr.grad) < TOL
+
+
 def _bn_cases():
     # (B, C, L, channel offset of the views inside wider buffers, extra channels of those buffers)
     return [(64, 24, 256, 0, 0), (64, 16, 256, 8, 16), (64, 16, 126, 0, 0), (64, 16, 126, 3, 5), (64, 12, 129, 0, 0), (64, 12, 61, 1, 2),
