@@ -91,7 +91,7 @@ def test_per_call_knobs_are_validated_and_steer_the_launch_plan():
     lib = _lib.load()
     d = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_FWD)
     # fp32 F / T: the one-wave-per-SIMD kernels (256 x 256 tiles, one workgroup per CU): 512 tiles = 2 whole tiles per CU
-    assert d.startswith("conv_raw3_kernel<32, 2, true>|") and "grid=512|tiles=512" in d and "split=0" in d
+    assert d.startswith("conv_raw3_kernel<32, 2, true, false>|") and "grid=512|tiles=512" in d and "split=0" in d
     dc = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_CONTENDED), _lib.OP_CONVT1D_FWD)
     assert "grid=1024" in dc and "split=1" in dc                       # data-parallel backward: keep the fine split
     dw = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_WGRAD)
@@ -101,7 +101,7 @@ def test_per_call_knobs_are_validated_and_steer_the_launch_plan():
     assert dd.startswith("conv_raw_kernel<32, 2, false, 0, 2>|") and "grid=1536|tiles=1056" in dd and "split=1" in dd and "whole=1024" in dd
     assert "whole=0" in ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_CONTENDED), _lib.OP_CONVT1D_DGRAD)
     da = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_ALL_RAW3), _lib.OP_CONVT1D_DGRAD)     # bit 14: 528 tiles = 2 x 256 whole + 16 split
-    assert da.startswith("conv_raw3_kernel<32, 2, false>|") and "grid=768|tiles=528" in da and "whole=512" in da
+    assert da.startswith("conv_raw3_kernel<32, 2, false, false>|") and "grid=768|tiles=528" in da and "whole=512" in da
     # bit 13: the two-waves-per-SIMD raw kernels (128 x 256 tiles, two workgroups per CU) as before round 3
     d2 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_NO_RAW3), _lib.OP_CONVT1D_FWD)
     assert d2.startswith("conv_raw_kernel<32, 2, true, 0, 2>|") and "grid=1024|tiles=1024" in d2 and "split=0" in d2

@@ -246,7 +246,7 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
         char name[96];
         if (g3) snprintf(name, sizeof name, "conv_g3_kernel<%d, %d, %s>", p.k, p.s, g3 == 1 ? "true" : "false");
         else if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_%s_kernel<%d, %d, %d>", p.g_ps ? "ps" : "raw", p.k, p.s, kn.prec);
-        else if (r3) snprintf(name, sizeof name, "conv_raw3_kernel<%d, %d, %s>", p.k, p.s, kind == KIND_T ? "true" : "false");
+        else if (r3) snprintf(name, sizeof name, "conv_raw3_kernel<%d, %d, %s, %s>", p.k, p.s, kind == KIND_T ? "true" : "false", p.act_x == PG_ACT_NONE ? "false" : "true");
         else if (raw) snprintf(name, sizeof name, "conv_raw_kernel<%d, %d, %s, %d, %d>", p.k, p.s, kind == KIND_T ? "true" : "false", kn.prec, tall ? 1 : 2);
         else snprintf(name, sizeof name, "conv_%c_kernel<%d, %d, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), spec ? p.k : 0, spec ? p.s : 0, kn.prec);
         snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", name, grid, tiles, p.nslab, (int)split, p.whole);

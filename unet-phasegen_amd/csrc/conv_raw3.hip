@@ -85,15 +85,17 @@ template <int JB, int P> __device__ __forceinline__ void r3_load_b(unsigned b_ad
     else asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=v"(t) : "v"(b_addr));
     f.d[JB][2 * P] = t[0]; f.d[JB][2 * P + 1] = t[1];
 }
-// window dwords -> B fragment elements (tap order) with the input activation max(v, slope v) (slope 1: the identity, exactly)
-template <bool DESC> __device__ __forceinline__ void r3_finish_b(R3Frag& f, float slope) {
+// window dwords -> B fragment elements (tap order); ACT: with the input activation max(v, slope v).  The engine's own calls store
+// activated tensors and load them as they are: that instantiation carries no VALU here (24 instructions per half-slab otherwise --
+// fix-ups cost MFMA issue slots even inside the gaps, conv_g3.hip).
+template <bool DESC, bool ACT> __device__ __forceinline__ void r3_finish_b(R3Frag& f, float slope) {
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int i = DESC ? 3 - kk : kk;
             const float v = __builtin_bit_cast(float, f.d[jb][i]);
-            f.b[jb][kk] = fmaxf(v, slope * v);
+            f.b[jb][kk] = ACT ? fmaxf(v, slope * v) : v;
         }
 }
 
@@ -101,7 +103,7 @@ template <bool DESC> __device__ __forceinline__ void r3_finish_b(R3Frag& f, floa
 // scheduling fences -- the reads of the NEXT half-slab's fragments `nxt` (window dwords behind MFMAs 0-3, weight rows behind 4-11),
 // gathers of the slab two ahead behind MFMAs 12, 16, ... 56 (`issue(E0 + n)`), the wait for the reads behind 60 and the activation
 // of the window values behind 61.
-template <int TJ, bool DESC, int RS, bool PM, int E0, typename Issue>
+template <int TJ, bool DESC, int RS, bool PM, bool ACT, int E0, typename Issue>
 __device__ __forceinline__ void r3_half(const R3Frag& cur, R3Frag& nxt, const float* nstage, int nc, int TA_, int r, int h,
                                         const int (&bbase)[2], float slope, AccT<8, 2>& acc, const Issue& issue) {
     const unsigned a0 = r3_a_addr<PM>(nstage, nc, r, h), a1 = PM ? r3_a_addr2<PM>(nstage, nc, r, h) : 0u;
@@ -141,7 +143,7 @@ __device__ __forceinline__ void r3_half(const R3Frag& cur, R3Frag& nxt, const fl
 #else
     R3_CHUNK(60, r3_lgkm0())
     __builtin_amdgcn_sched_barrier(0);
-    R3_CHUNK(61, r3_finish_b<DESC>(nxt, slope))
+    R3_CHUNK(61, (r3_finish_b<DESC, ACT>(nxt, slope)))
 #endif
     R3_CHUNK(62, (void)0)
     R3_CHUNK(63, (void)0)
@@ -161,7 +163,7 @@ __device__ __forceinline__ void store_partial_r3(float* ws, int g, int slot, con
 }
 
 // TKIND false: F (conv fwd / convT dgrad);  TKIND true: T (convT fwd / conv dgrad in gather form)
-template <int KW, int S, bool TKIND>
+template <int KW, int S, bool TKIND, bool ACT>
 __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) {
     constexpr int TM = R3_TM, TN = R3_TN;
     constexpr int TA = TM * BK;                       // floats of the weight tile (16 KB)
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
             r3_load_a<PM, 4>(a0, a1, f0); r3_load_a<PM, 5>(a0, a1, f0); r3_load_a<PM, 6>(a0, a1, f0); r3_load_a<PM, 7>(a0, a1, f0);
             r3_lgkm0();
             __builtin_amdgcn_sched_barrier(0);
-            r3_finish_b<TKIND>(f0, slopeB);
+            r3_finish_b<TKIND, ACT>(f0, slopeB);
         }
         int st = 0;
         for (int sl = sb; sl < se; ++sl) {
@@ -326,11 +328,11 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
             const int s2 = sl + 2;
             auto issue0 = [&](int e) { if (e < ND0) issue_piece(ring2, s2, e); };             // first half: gathers 0 ... ND0 - 1
             auto issue1 = [&](int e) { if (e < ND) issue_piece(ring2, s2, e); };              // second half: the rest (E0 = ND0)
-            r3_half<TJ, TKIND, RS, PM, 0>(f0, f1, cur, 1, TA, r, h, bbase, slopeB, acc, issue0);
+            r3_half<TJ, TKIND, RS, PM, ACT, 0>(f0, f1, cur, 1, TA, r, h, bbase, slopeB, acc, issue0);
             // (past the last slab of the segment the "next" stage holds zero-filled or older slabs: read, never multiplied; f0 is
             // carried by the loop, so its registers stay reserved until the reads have landed -- conv_h3.hip on dead asm reads)
             wait_next();
-            r3_half<TJ, TKIND, RS, PM, ND0>(f1, f0, lds + st1 * STG, 0, TA, r, h, bbase, slopeB, acc, issue1);
+            r3_half<TJ, TKIND, RS, PM, ACT, ND0>(f1, f0, lds + st1 * STG, 0, TA, r, h, bbase, slopeB, acc, issue1);
             st = st1;
         }
         __syncthreads();
@@ -393,15 +395,19 @@ __global__ __launch_bounds__(NT3) void conv_raw3_fixup_kernel(const IgemmParams 
     else epilogue_t_pm<1, 1>(p, acc, mt / 2 + (bi >> 1) * 32, n0, lane, bi & 1);
 }
 
-template <int KW, int S, bool TK>
-hipError_t launch3(const IgemmParams& p, int grid, hipStream_t st) {
+template <int KW, int S, bool TK, bool ACT>
+hipError_t launch3a(const IgemmParams& p, int grid, hipStream_t st) {
     constexpr int KWP = TK ? KW / S : KW, TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ, SC = TK ? 1 : S;
     constexpr int lds_bytes = R3_RING * (R3_TM * BK + NQ * (SC == 1 ? RS1 : RS2)) * 4;
     // (the attribute belongs to (function, current device): set on every call, nothing cached between calls)
-    hipError_t e = hipFuncSetAttribute((const void*)conv_raw3_kernel<KW, S, TK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_raw3_kernel<KW, S, TK, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((conv_raw3_kernel<KW, S, TK>), dim3(grid), dim3(NT3), lds_bytes, st, p);
+    hipLaunchKernelGGL((conv_raw3_kernel<KW, S, TK, ACT>), dim3(grid), dim3(NT3), lds_bytes, st, p);
     return hipGetLastError();
+}
+template <int KW, int S, bool TK>
+hipError_t launch3(const IgemmParams& p, int grid, hipStream_t st) {
+    return p.act_x == PG_ACT_NONE ? launch3a<KW, S, TK, false>(p, grid, st) : launch3a<KW, S, TK, true>(p, grid, st);
 }
 
 }  // namespace
