@@ -12,7 +12,7 @@
 //     of 16 consecutive samples form rem "leftover" slabs whose 16 k-elements are 16 SAMPLES at one frame: A tile and B tile (a plain
 //     [16][256] matrix: every (sample, column) value once) gathered element-wise, 32 dword gathers per wave -- 1 slab in 129.
 //     K = B * LP exactly: no padded work.
-// Everything else (k = 5, bf16 operand modes, other batch sizes) stays on conv_raw_wgrad.hip.
+// Everything else (k = 5, bf16 operand modes, other batch sizes, an activation applied on load) stays on conv_raw_wgrad.hip.
 #include "conv_common.h"
 
 namespace {
@@ -127,32 +127,18 @@ __device__ __forceinline__ void g3_half(const G3Frag& cur, G3Frag& nxt, unsigned
     WORK;
 #define G3_LB(JB, P) { if (!PAD && fx.left) g3_load_b_left<JB, P>(JB ? b1 : b0, nxt); else g3_load_b_main<S, JB, P>(JB ? b1 : b0, nxt); }
     // Fix-ups cost MFMA issue slots even inside the gaps (measured: always-on select + multiply + two max per value -- 365 VALU per
-    // slab -- took the kernel from 0.88 to 0.78 of the pipe), so each is behind a wave-uniform test and as short as it gets:
-    // ReLU = one v_max, LeakyReLU = v_mul + v_max (asm: fmaxf() adds a canonicalising max per value), nothing for the identity;
-    // the zeroing of frames past the sample's end only on a sample's last slab, the range check only where the window leaves the row.
-#if defined(PG_G3_ABL) && PG_G3_ABL == 1       /* dev ablation (wrong results with activations / padding): no weight-row fix-ups */
-#define G3_FA(I) {}
-#else
+    // slab -- took the kernel from 0.88 to 0.78 of the pipe; the same behind wave-uniform tests -- ~40 scalar branches per slab --
+    // cost as much).  This kernel therefore covers the case the engine uses -- operands stored activated, loaded as they are -- and
+    // carries only: PAD, the zeroing of frames past the sample's end (always on: 4 compares + 4 selects per row block); the range
+    // check of window values (always on: add + compare + select per value).
 #define G3_FA(I) {                                                                                                               \
-        if (PAD && fx.kc < 16) {                                                                                                 \
+        if (PAD) {                                                                                                               \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) nxt.a[I][kk] = (8 * h + 4 * c + kk < fx.kc) ? nxt.a[I][kk] : 0.f;   \
-        }                                                                                                                        \
-        if (slopeA == 0.f) {                                                                                                     \
-            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) nxt.a[I][kk] = g3_relu(nxt.a[I][kk]);                               \
-        } else if (slopeA != 1.0f) {                                                                                             \
-            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) nxt.a[I][kk] = g3_leaky(nxt.a[I][kk], slopeA);                      \
         } }
-#endif
 #define G3_FB(JB) {                                                                                                              \
-        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) nxt.b[JB][kk] = __builtin_bit_cast(float, nxt.d[JB][kk]);               \
-        if (!(!PAD && fx.left) && fx.edge) {                                                                                     \
-            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                                     \
-                nxt.b[JB][kk] = (unsigned)(fx.w0 + pj[JB] + S * (4 * c + kk)) < (unsigned)Lx ? nxt.b[JB][kk] : 0.f;              \
-        }                                                                                                                        \
-        if (slopeB == 0.f) {                                                                                                     \
-            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) nxt.b[JB][kk] = g3_relu(nxt.b[JB][kk]);                             \
-        } else if (slopeB != 1.0f) {                                                                                             \
-            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) nxt.b[JB][kk] = g3_leaky(nxt.b[JB][kk], slopeB);                    \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                                       \
+            const float v = __builtin_bit_cast(float, nxt.d[JB][kk]);                                                            \
+            nxt.b[JB][kk] = ((!PAD && fx.left) || (unsigned)(fx.w0 + pj[JB] + S * (4 * c + kk)) < (unsigned)Lx) ? v : 0.f;       \
         } }
     G3_CHUNK(0, G3_LB(0, 0)) G3_CHUNK(1, G3_LB(0, 1)) G3_CHUNK(2, G3_LB(1, 0)) G3_CHUNK(3, G3_LB(1, 1))
     G3_CHUNK(4, g3_load_a<0>(a0, nxt)) G3_CHUNK(5, g3_load_a<1>(a0, nxt)) G3_CHUNK(6, g3_load_a<2>(a0, nxt)) G3_CHUNK(7, g3_load_a<3>(a0, nxt))
@@ -204,7 +190,8 @@ __global__ __launch_bounds__(NT3, 1) void conv_g3_kernel(const IgemmParams p) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wv;
     const int r = lane & 31, h = lane >> 5;
     const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
-    const float slopeA = act_slope(p.act_p), slopeB = act_slope(p.act_x);
+    const float slopeA = 1.0f, slopeB = 1.0f;       // (host: this kernel only where neither operand has an activation on load)
+    (void)slopeA; (void)slopeB;
     const int pbs4 = (int)p.pt_bs * 4, xbs4 = (int)p.x_bs * 4;
     const int cf = PAD ? (p.LP + 15) >> 4 : p.LP >> 4;               // main slabs per sample
     const int rem = PAD ? 0 : p.LP & 15;                             // leftover frames per sample
@@ -334,7 +321,7 @@ __global__ __launch_bounds__(NT3, 1) void conv_g3_kernel(const IgemmParams p) {
                 for (int kk = 0; kk < 4; ++kk) {
                     float v = f0.a[i][kk];
                     if (PAD) v = (8 * h + kk < fx.kc) ? v : 0.f;
-                    f0.a[i][kk] = fmaxf(v, slopeA * v);
+                    f0.a[i][kk] = v;
                 }
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
@@ -342,7 +329,7 @@ __global__ __launch_bounds__(NT3, 1) void conv_g3_kernel(const IgemmParams p) {
                 for (int kk = 0; kk < 4; ++kk) {
                     float v = __builtin_bit_cast(float, f0.d[jb][kk]);
                     if (!fx.left) v = (unsigned)(fx.w0 + pj[jb] + S * kk) < (unsigned)p.Lx ? v : 0.f;
-                    f0.b[jb][kk] = fmaxf(v, slopeB * v);
+                    f0.b[jb][kk] = v;
                 }
         }
         int st = 0;

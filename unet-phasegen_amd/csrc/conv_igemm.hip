@@ -204,6 +204,7 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     // (DESIGN.md section 4.1b).
     int g3 = 0;
     if (raw && kind == KIND_G && kn.prec == 0 && kn.all_raw3 && !kn.no_ps && (p.k == 32 || p.k == 8 || p.k == 4) &&
+        p.act_x == PG_ACT_NONE && p.act_p == PG_ACT_NONE &&
         (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103) {
         const long cps = (p.LP + 15) / 16, rem = p.LP % 16;
         if (rem && rem <= 2 && p.B % 16 == 0 && (cps * 16 - p.LP) * 100 > 2L * p.LP) { g3 = 2; Ktot = (long)p.B * p.LP; }
