@@ -207,3 +207,32 @@ def test_conv_fwd_h_random_geometries(geom):
     else:
         with pytest.raises(RuntimeError, match="not covered"):
             ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y)
+
+
+@pytest.mark.parametrize("geom", [(True, 128, 250, 32, 2, 16, 129, 4), (False, 64, 500, 8, 1, 2, 126, 6), (True, 256, 125, 8, 2, 1, 61, 8),
+                                  (False, 64, 250, 4, 2, 1, 62, 16), (False, 32, 250, 32, 2, 16, 256, 16)],
+                         ids=["T-k32", "F-k8s1", "T-k8s2", "F-k4", "F-k32"])
+def test_conv_h3_is_race_free_by_repetition(geom):
+    """conv_h3.hip (the default family) orders its LDS traffic with counted vmcnt waits, a raw s_barrier per stage group and
+    loop-carried asm reads -- nothing the compiler checks.  A misplaced wait shows as results that change from launch to launch:
+    40 launches under the forced stream-K split and with one tile per workgroup must be bit-identical to the first, which itself is
+    checked against the float64 convolution of the bf16 operands."""
+    from phasegen import ops
+    tr, Cin, Cout, k, s, p, Lin, B = geom
+    x = rnd(41, B, Cin, Lin)
+    w = rnd(42, *((Cin, Cout, k) if tr else (Cout, Cin, k))) * 0.1
+    want = (F.conv_transpose1d if tr else F.conv1d)(x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), stride=s, padding=p)
+    assert ops.conv_fwd_h_supported(B, tuple(w.shape), Lin, s, p, tr)
+    xh = ops.h_alloc(B, Cin, Lin, "cuda")
+    ops.cast_rows_bf16(x.cuda(), xh)
+    wh = ops.shadow_weights(w.cuda(), tr, s)
+    for sched in (4096 | 2, 4096 | 1):
+        first = None
+        for it in range(40):
+            y = torch.empty(tuple(want.shape), device="cuda")
+            ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y, schedule=sched)
+            if first is None:
+                first = y
+                assert relerr(y, want) < 2e-5
+            else:
+                assert torch.equal(y, first), (sched, it)

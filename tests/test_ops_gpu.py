@@ -435,6 +435,41 @@ def test_conv_random_geometries_one_wave_kernels(geom, sched):
     assert relerr(y, yr) < TOL and relerr(dx, want_dx) < TOL and relerr(dw, wr.grad) < TOL
 
 
+@pytest.mark.parametrize("geom", [(True, 96, 250, 32, 2, 16, 129, 4), (False, 64, 500, 8, 1, 2, 126, 6), (True, 128, 125, 8, 2, 1, 61, 8),
+                                  (False, 48, 250, 4, 2, 1, 62, 16), (False, 32, 250, 32, 2, 16, 256, 16)],
+                         ids=["T-k32", "F-k8s1", "T-k8s2", "F-k4", "F-k32"])
+def test_one_wave_kernels_are_race_free_by_repetition(geom):
+    """The one-wave-per-SIMD kernels order their LDS traffic with counted vmcnt waits, one raw s_barrier per slab and loop-carried
+    asm reads -- nothing the compiler checks.  A misplaced wait shows as results that change from launch to launch (the DMA sometimes
+    lands first): 40 launches each of forward / dgrad / wgrad under the forced stream-K split (partial tiles, fixup) and with one tile per
+    workgroup must be bit-identical to the first, which itself is checked against torch."""
+    from phasegen import ops
+    tr, Cin, Cout, k, s, p, Lin, B = geom
+    x = rnd(31, B, Cin, Lin)
+    w = rnd(32, *((Cin, Cout, k) if tr else (Cout, Cin, k))) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv_transpose1d(xr, wr, stride=s, padding=p) if tr else F.conv1d(xr, wr, stride=s, padding=p)
+    dy = rnd(33, *yr.shape)
+    yr.backward(dy)
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    for sched in (0x4000 | 2, 0x4000 | 1):
+        ops.set_conv_schedule(sched)
+        try:
+            first = None
+            for it in range(40):
+                y = torch.empty(yr.shape, device="cuda"); dx = torch.empty(x.shape, device="cuda"); dw = torch.empty(w.shape, device="cuda")
+                ops.conv_fwd(xd, wd, y, s, p, transposed=tr)
+                ops.conv_dgrad(dyd, wd, dx, s, p, transposed=tr)
+                ops.conv_wgrad(xd, dyd, dw, s, p, transposed=tr)
+                if first is None:
+                    first = (y, dx, dw)
+                    assert relerr(y, yr) < TOL and relerr(dx, xr.grad) < TOL and relerr(dw, wr.grad) < TOL
+                else:
+                    assert torch.equal(y, first[0]) and torch.equal(dx, first[1]) and torch.equal(dw, first[2]), (sched, it)
+        finally:
+            ops.set_conv_schedule(0)
+
+
 def _bn_cases():
     # (B, C, L, channel offset of the views inside wider buffers, extra channels of those buffers)
     return [(64, 24, 256, 0, 0), (64, 16, 256, 8, 16), (64, 16, 126, 0, 0), (64, 16, 126, 3, 5), (64, 12, 129, 0, 0), (64, 12, 61, 1, 2),
