@@ -125,7 +125,11 @@ __device__ __forceinline__ void g3_half(const G3Frag& cur, G3Frag& nxt, unsigned
     acc.c[((C) >> 1) & 7][(C) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[((C) >> 1) & 7][(C) >> 4], cur.b[(C) & 1][(C) >> 4], \
                                                                          acc.c[((C) >> 1) & 7][(C) & 1], 0, 0, 0);               \
     WORK;
+#if defined(PG_G3_ABL) && PG_G3_ABL == 3
+#define G3_LB(JB, P) { g3_load_b_main<S, JB, P>(JB ? b1 : b0, nxt); }
+#else
 #define G3_LB(JB, P) { if (!PAD && fx.left) g3_load_b_left<JB, P>(JB ? b1 : b0, nxt); else g3_load_b_main<S, JB, P>(JB ? b1 : b0, nxt); }
+#endif
     // Fix-ups cost MFMA issue slots even inside the gaps (measured: always-on select + multiply + two max per value -- 365 VALU per
     // slab -- took the kernel from 0.88 to 0.78 of the pipe; the same behind wave-uniform tests -- ~40 scalar branches per slab --
     // cost as much).  This kernel therefore covers the case the engine uses -- operands stored activated, loaded as they are -- and
@@ -135,11 +139,15 @@ __device__ __forceinline__ void g3_half(const G3Frag& cur, G3Frag& nxt, unsigned
         if (PAD) {                                                                                                               \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) nxt.a[I][kk] = (8 * h + 4 * c + kk < fx.kc) ? nxt.a[I][kk] : 0.f;   \
         } }
+#if defined(PG_G3_ABL) && PG_G3_ABL >= 2      /* dev ablation (wrong results): no range selects; 3: no leftover-type branches either */
+#define G3_FB(JB) { _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) nxt.b[JB][kk] = __builtin_bit_cast(float, nxt.d[JB][kk]); }
+#else
 #define G3_FB(JB) {                                                                                                              \
         _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                                       \
             const float v = __builtin_bit_cast(float, nxt.d[JB][kk]);                                                            \
             nxt.b[JB][kk] = ((!PAD && fx.left) || (unsigned)(fx.w0 + pj[JB] + S * (4 * c + kk)) < (unsigned)Lx) ? v : 0.f;       \
         } }
+#endif
     G3_CHUNK(0, G3_LB(0, 0)) G3_CHUNK(1, G3_LB(0, 1)) G3_CHUNK(2, G3_LB(1, 0)) G3_CHUNK(3, G3_LB(1, 1))
     G3_CHUNK(4, g3_load_a<0>(a0, nxt)) G3_CHUNK(5, g3_load_a<1>(a0, nxt)) G3_CHUNK(6, g3_load_a<2>(a0, nxt)) G3_CHUNK(7, g3_load_a<3>(a0, nxt))
     G3_CHUNK(8, g3_load_a<4>(a0, nxt)) G3_CHUNK(9, g3_load_a<5>(a0, nxt)) G3_CHUNK(10, g3_load_a<6>(a0, nxt)) G3_CHUNK(11, g3_load_a<7>(a0, nxt))
