@@ -50,14 +50,6 @@ __device__ __forceinline__ float g3_acc(float v) {
     return x;
 }
 
-// max(v, 0) and max(v, slope v) without fmaxf()'s canonicalising extra instruction
-__device__ __forceinline__ float g3_relu(float v) { float x; asm("v_max_f32 %0, 0, %1" : "=v"(x) : "v"(v)); return x; }
-__device__ __forceinline__ float g3_leaky(float v, float slope) {
-    float t = slope * v, x;
-    asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(v), "v"(t));
-    return x;
-}
-
 // position of a slab in the K order: sample smp of group g (PAD: groups of one sample; leftover variant: of 16), chunk chk of its
 // whole 16-frame chunks -- or, left = 1, leftover frame t of the group's 16 samples.  Wave-uniform scalars, advanced incrementally.
 struct G3Pos { int g, smp, chk, left; };
@@ -111,15 +103,14 @@ struct G3Fix { int left; int w0; int kc; int edge; };   // leftover slab?; main:
 
 // One half-slab: the 64 MFMAs of `cur` and, one piece per MFMA gap, the reads of the next half-slab `nxt` (window dwords behind MFMAs
 // 0-3, weight rows behind 4-11), gathers of the slab two ahead behind the even MFMAs 12 ... 62 (`issue(E0 + n)`), the wait for the
-// reads behind 24 and the fix-ups of `nxt` behind the odd MFMAs 25 ... 59: activation (and, PAD, zeroing of frames past LP) of the
-// weight-row fragments one row block at a time, range check + activation of the window values.
+// reads behind 24 and the fix-ups of `nxt` behind the odd MFMAs 25 ... 43: PAD, zeroing of frames past LP in the weight-row fragments
+// one row block at a time; range check of the window values.
 // (ONE instantiation serves both slab types: the type only selects the B read instruction -- a two-instruction wave-uniform branch
 // inside the gap -- and switches the range check off.  With the MFMA stream itself duplicated under an if / else, hipcc no longer
 // kept the 256 accumulators in place across the join and spilled ~650 registers.)
 template <int S, bool PAD, int E0, typename Issue>
 __device__ __forceinline__ void g3_half(const G3Frag& cur, G3Frag& nxt, unsigned a0, unsigned b0, unsigned b1, int c, int h,
-                                        const G3Fix fx, const int (&pj)[2], int Lx, float slopeA, float slopeB,
-                                        AccT<8, 2>& acc, const Issue& issue) {
+                                        const G3Fix fx, const int (&pj)[2], int Lx, AccT<8, 2>& acc, const Issue& issue) {
 #define G3_CHUNK(C, WORK)                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                                           \
     acc.c[((C) >> 1) & 7][(C) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[((C) >> 1) & 7][(C) >> 4], cur.b[(C) & 1][(C) >> 4], \
@@ -198,8 +189,7 @@ __global__ __launch_bounds__(NT3, 1) void conv_g3_kernel(const IgemmParams p) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wv;
     const int r = lane & 31, h = lane >> 5;
     const rsrc_t rp = make_rsrc(p.pt, p.pt_bytes), rx = make_rsrc(p.x, p.x_bytes);
-    const float slopeA = 1.0f, slopeB = 1.0f;       // (host: this kernel only where neither operand has an activation on load)
-    (void)slopeA; (void)slopeB;
+    // (host: this kernel only where neither operand has an activation on load)
     const int pbs4 = (int)p.pt_bs * 4, xbs4 = (int)p.x_bs * 4;
     const int cf = PAD ? (p.LP + 15) >> 4 : p.LP >> 4;               // main slabs per sample
     const int rem = PAD ? 0 : p.LP & 15;                             // leftover frames per sample
@@ -355,7 +345,7 @@ __global__ __launch_bounds__(NT3, 1) void conv_g3_kernel(const IgemmParams p) {
                 const unsigned a0 = g3_a_addr(cur, 1, r, h);
                 const unsigned bb = g3_lds_addr(cur + TA) + (fx.left ? 4 * G3_TN * 4 : S * 4 * 4);
                 g3_half<S, PAD, 0>(f0, f1, a0, bb + (fx.left ? bcol[0] : bbase[0]) * 4, bb + (fx.left ? bcol[1] : bbase[1]) * 4, 1, h, fx, pj, p.Lx,
-                                   slopeA, slopeB, acc, issue0);
+                                   acc, issue0);
             }
             // In front of the second half, whose gaps carry the reads of slab sl + 1's first fragments: of slab sl + 2's gathers this
             // wave has issued min(26, its count) -- they may stay in flight, everything older (slab sl + 1) is done.  The barrier also
@@ -369,7 +359,7 @@ __global__ __launch_bounds__(NT3, 1) void conv_g3_kernel(const IgemmParams p) {
                 const unsigned a0 = g3_a_addr(nxs, 0, r, h);
                 const unsigned bb = g3_lds_addr(nxs + TA);
                 g3_half<S, PAD, G3_SLOTS>(f1, f0, a0, bb + (fx.left ? bcol[0] : bbase[0]) * 4, bb + (fx.left ? bcol[1] : bbase[1]) * 4, 0, h, fx, pj,
-                                          p.Lx, slopeA, slopeB, acc, issue0);
+                                          p.Lx, acc, issue0);
             }
             s0 = s1; s1 = s2;
             g3_advance<PAD>(s2, cf, rem);
