@@ -96,12 +96,9 @@ def test_per_call_knobs_are_validated_and_steer_the_launch_plan():
     assert "grid=1024" in dc and "split=1" in dc                       # data-parallel backward: keep the fine split
     dw = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_WGRAD)
     assert "grid=2048|tiles=8192" in dw and "split=0" in dw            # 4 whole tiles per workgroup: no fixup either
-    # the F form of k = 32 stays on the 128 x 256 kernel by default: 1056 tiles = 2 x 512 whole + 32 split over 512 more
-    dd = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_DGRAD)
-    assert dd.startswith("conv_raw_kernel<32, 2, false, 0, 2>|") and "grid=1536|tiles=1056" in dd and "split=1" in dd and "whole=1024" in dd
+    dd = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_DGRAD)       # 528 tiles = 2 x 256 whole + 16 split over 256 more
+    assert dd.startswith("conv_raw3_kernel<32, 2, false, false>|") and "grid=768|tiles=528" in dd and "split=1" in dd and "whole=512" in dd
     assert "whole=0" in ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_CONTENDED), _lib.OP_CONVT1D_DGRAD)
-    da = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_ALL_RAW3), _lib.OP_CONVT1D_DGRAD)     # bit 14: 528 tiles = 2 x 256 whole + 16 split
-    assert da.startswith("conv_raw3_kernel<32, 2, false, false>|") and "grid=768|tiles=528" in da and "whole=512" in da
     # bit 13: the two-waves-per-SIMD raw kernels (128 x 256 tiles, two workgroups per CU) as before round 3
     d2 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_NO_RAW3), _lib.OP_CONVT1D_FWD)
     assert d2.startswith("conv_raw_kernel<32, 2, true, 0, 2>|") and "grid=1024|tiles=1024" in d2 and "split=0" in d2
@@ -114,7 +111,7 @@ def test_per_call_knobs_are_validated_and_steer_the_launch_plan():
     assert "split=0" in one and "grid=512|tiles=512" in one
     g4 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_FORCE_STREAMK), _lib.OP_CONVT1D_DGRAD)
     g1 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_FORCE_STREAMK | (1 << 8)), _lib.OP_CONVT1D_DGRAD)   # oversubscribe factor 1
-    assert "grid=2048" in g4 and "grid=512" in g1
+    assert "grid=1024" in g4 and "grid=256" in g1
     buf = ctypes.create_string_buffer(256)
     assert lib.pg_conv_describe(ctypes.byref(_u0_args(lib, precision=3)), 3, buf, 256) == -4      # PG_ERR_UNSUPPORTED
     assert lib.pg_conv_describe(ctypes.byref(_u0_args(lib, schedule=3)), 3, buf, 256) == -2       # PG_ERR_SHAPE

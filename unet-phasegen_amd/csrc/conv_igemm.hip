@@ -212,14 +212,11 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     }
     // fp32 F / T problems the one-wave-per-SIMD kernels cover (conv_raw3.hip: 256 x 256 tile) take them, unless 256-row tiles
     // would compute over 3 % more rows than 128-row ones
-    // Not (by default) the F form of k = 32: its weight tile gathers 64-byte row segments (16 rows per instruction, against 8 whole
-    // 128-byte lines in the phase-major T image), which costs the one-wave kernel 2.5 % where the T form pays 0.9 %: measured level
-    // with the 128 x 256 kernel or 1 % behind (U0 dgrad 31.4 vs 31.1 ms, D0 forward 7.9 vs 7.8).
     // Over the tall tile too where 256-wide tiles compute at most 8 % more columns (D2 forward / U2 dgrad / D3 forward at batch 64:
     // -6 / -2 / -6 %, and 2.2 instead of 6.95 GB of L2 fills; batch-1 inference and N = 16 x 65 keep the tall tile).
     const bool r3_over_tall = tall && raw_supported(kind, p, kn) && (kn.all_raw3 || cols_wide * 100 <= cols_tall * 108);
     const bool r3 = raw && (!tall || r3_over_tall) && kind != KIND_G && kn.prec == 0 && !kn.no_raw3 && pgconv::raw3_covers(kind, p) &&
-                    (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103 && (kn.all_raw3 || !(kind == KIND_F && p.k == 32));
+                    (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103;
     const int bm = (tall || r3 || g3) ? 2 * RBM : (raw ? RBM : BM);
     int bn = (tall && !r3) ? RBN / 2 : (raw ? RBN : BN);
     const bool k5 = raw && p.k == 5 && p.s == 2;
