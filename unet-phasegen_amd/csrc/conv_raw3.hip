@@ -12,7 +12,7 @@
 // slabs ahead behind a counted vmcnt, one raw s_barrier per slab (8192 MFMA cycles) placed in front of the slab's second half, whose
 // gaps carry the reads of the next slab's first fragments.
 //
-// Covered: fp32 operands (precision 0), F: k = 32 / 8 / 4 at stride 2 and k = 8 at stride 1; T: k = 32 / 8 at stride 2 (phase-major
+// Covered: fp32 operands (precision 0), F: k = 32 / 8 / 4 at stride 2 and k = 8 at stride 1; T: k = 32 / 8 / 4 at stride 2 (phase-major
 // weight image), k = 8 at stride 1; whole 16-deep slabs only (Cin a multiple of 16 / taps-per-channel).  Everything else -- k = 5,
 // the bf16 operand modes, K tails, small problems -- stays on conv_raw.hip / conv_raw_tall.hip / conv_im2col.hip.
 #include "conv_common.h"
@@ -71,29 +71,33 @@ template <bool PM> __device__ __forceinline__ float r3_a_elem(const R3Frag& f, i
     return f.a[i][kk];
 }
 // byte address of the first of the four dwords of column block jb in half-slab c.  TJ = taps per channel and slab (16: one channel,
-// lane half h takes taps 8 h ..; 8: channel h; 4: channels 2 h + c), DESC: taps descend (stored ascending from base - (TD - 1)).
+// lane half h takes taps 8 h ..; 8: channel h; 4: channels 2 h + c; 2: channels 4 h + 2 c, + 1), DESC: taps descend (stored ascending from
+// base - (TD - 1)).
 template <int TJ, bool DESC, int RS>
 __device__ __forceinline__ unsigned r3_b_addr(const float* bw, int c, int h, int bbase_jb) {
     constexpr int TD = TJ < 8 ? TJ : 8;
     const int lanepart = (TJ == 16) ? (DESC ? -8 * h : 8 * h) : (8 / TJ) * h * RS;
-    const int so = TJ >= 8 ? (DESC ? 4 - 4 * c : 4 * c) : c * RS;          // TJ = 4: TD = 4, the half-slab is one channel's four taps
+    // TJ = 4: the half-slab is one channel's four taps; TJ = 2: two channels' two taps each (the second RS floats further: r3_load_b)
+    const int so = TJ >= 8 ? (DESC ? 4 - 4 * c : 4 * c) : (TJ == 4 ? c * RS : 2 * c * RS);
     return r3_lds_addr(bw) + (bbase_jb + lanepart - (DESC ? TD - 1 : 0) + so) * 4;
 }
-template <int JB, int P> __device__ __forceinline__ void r3_load_b(unsigned b_addr, R3Frag& f) {
+// W2 = byte distance of the pair's second read: 0 -> dwords 2, 3 of the same run; else (TJ = 2) dwords 0, 1 of the next channel's window
+template <int JB, int P, int W2 = 0> __device__ __forceinline__ void r3_load_b(unsigned b_addr, R3Frag& f) {
     u32x2v t;
     if (P == 0) asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(t) : "v"(b_addr));
-    else asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=v"(t) : "v"(b_addr));
+    else if (W2 == 0) asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=v"(t) : "v"(b_addr));
+    else asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(t) : "v"(b_addr + W2));
     f.d[JB][2 * P] = t[0]; f.d[JB][2 * P + 1] = t[1];
 }
 // window dwords -> B fragment elements (tap order); ACT: with the input activation max(v, slope v).  The engine's own calls store
 // activated tensors and load them as they are: that instantiation carries no VALU here (24 instructions per half-slab otherwise --
 // fix-ups cost MFMA issue slots even inside the gaps, conv_g3.hip).
-template <bool DESC, bool ACT> __device__ __forceinline__ void r3_finish_b(R3Frag& f, float slope) {
+template <bool DESC, bool ACT, bool TJ2 = false> __device__ __forceinline__ void r3_finish_b(R3Frag& f, float slope) {
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int i = DESC ? 3 - kk : kk;
+            const int i = DESC ? (TJ2 ? kk ^ 1 : 3 - kk) : kk;        // (two taps per channel: the descending order is per channel)
             const float v = __builtin_bit_cast(float, f.d[jb][i]);
             f.b[jb][kk] = ACT ? fmaxf(v, slope * v) : v;
         }
@@ -120,7 +124,8 @@ __device__ __forceinline__ void r3_half(const R3Frag& cur, R3Frag& nxt, const fl
     R3_ROW(4, (void)0, (void)0, (void)0, (void)0)
     R3_ROW(8, (void)0, (void)0, (void)0, (void)0)
 #else
-    R3_ROW(0, (r3_load_b<0, 0>(b0, nxt)), (r3_load_b<0, 1>(b0, nxt)), (r3_load_b<1, 0>(b1, nxt)), (r3_load_b<1, 1>(b1, nxt)))
+    constexpr int W2 = TJ == 2 ? RS * 4 : 0;
+    R3_ROW(0, (r3_load_b<0, 0, W2>(b0, nxt)), (r3_load_b<0, 1, W2>(b0, nxt)), (r3_load_b<1, 0, W2>(b1, nxt)), (r3_load_b<1, 1, W2>(b1, nxt)))
     R3_ROW(4, (r3_load_a<PM, 0>(a0, a1, nxt)), (r3_load_a<PM, 1>(a0, a1, nxt)), (r3_load_a<PM, 2>(a0, a1, nxt)), (r3_load_a<PM, 3>(a0, a1, nxt)))
     R3_ROW(8, (r3_load_a<PM, 4>(a0, a1, nxt)), (r3_load_a<PM, 5>(a0, a1, nxt)), (r3_load_a<PM, 6>(a0, a1, nxt)), (r3_load_a<PM, 7>(a0, a1, nxt)))
 #endif
@@ -143,7 +148,7 @@ __device__ __forceinline__ void r3_half(const R3Frag& cur, R3Frag& nxt, const fl
 #else
     R3_CHUNK(60, r3_lgkm0())
     __builtin_amdgcn_sched_barrier(0);
-    R3_CHUNK(61, (r3_finish_b<DESC, ACT>(nxt, slope)))
+    R3_CHUNK(61, (r3_finish_b<DESC, ACT, TJ == 2>(nxt, slope)))
 #endif
     R3_CHUNK(62, (void)0)
     R3_CHUNK(63, (void)0)
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
     constexpr int STG = TA + NQ * RS;                 // floats per LDS stage (one slab)
     constexpr int ND = AE16 + NQ * NPC;               // gathers per wave and slab
     constexpr int ND0 = ND < R3_SLOTS ? ND : R3_SLOTS;   // ... of them issued in the slab's first half
-    static_assert(TJ == 4 || TJ == 8 || TJ == 16, "taps per channel and slab");
+    static_assert(TJ == 2 || TJ == 4 || TJ == 8 || TJ == 16, "taps per channel and slab");
     static_assert(ND <= 2 * R3_SLOTS && ND < 32, "gather slots per slab / vmcnt range");
     static_assert(R3_RING * STG * 4 <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -313,12 +318,13 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
         {
             const unsigned a0 = r3_a_addr<PM>(lds, 0, r, h), a1 = PM ? r3_a_addr2<PM>(lds, 0, r, h) : 0u;
             const unsigned b0a = r3_b_addr<TJ, TKIND, RS>(lds + TA, 0, h, bbase[0]), b1a = r3_b_addr<TJ, TKIND, RS>(lds + TA, 0, h, bbase[1]);
-            r3_load_b<0, 0>(b0a, f0); r3_load_b<0, 1>(b0a, f0); r3_load_b<1, 0>(b1a, f0); r3_load_b<1, 1>(b1a, f0);
+            constexpr int W2 = TJ == 2 ? RS * 4 : 0;
+            r3_load_b<0, 0, W2>(b0a, f0); r3_load_b<0, 1, W2>(b0a, f0); r3_load_b<1, 0, W2>(b1a, f0); r3_load_b<1, 1, W2>(b1a, f0);
             r3_load_a<PM, 0>(a0, a1, f0); r3_load_a<PM, 1>(a0, a1, f0); r3_load_a<PM, 2>(a0, a1, f0); r3_load_a<PM, 3>(a0, a1, f0);
             r3_load_a<PM, 4>(a0, a1, f0); r3_load_a<PM, 5>(a0, a1, f0); r3_load_a<PM, 6>(a0, a1, f0); r3_load_a<PM, 7>(a0, a1, f0);
             r3_lgkm0();
             __builtin_amdgcn_sched_barrier(0);
-            r3_finish_b<TKIND, ACT>(f0, slopeB);
+            r3_finish_b<TKIND, ACT, TJ == 2>(f0, slopeB);
         }
         int st = 0;
         for (int sl = sb; sl < se; ++sl) {
@@ -416,7 +422,7 @@ bool pgconv::raw3_covers(int kind, const IgemmParams& p) {
     if (kind == KIND_F) {
         if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
     } else if (kind == KIND_T) {
-        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2))) return false;
+        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
     } else return false;
     const int kwp = kind == KIND_T ? p.k / p.s : p.k, tj = kwp < 16 ? kwp : 16;
     return ((long)p.Q * kwp) % BK == 0 && p.Q % (16 / tj > 0 ? 16 / tj : 1) == 0;     // whole slabs of whole channels only
@@ -430,6 +436,7 @@ hipError_t pgconv::launch_raw3(int kind, const IgemmParams& p, int grid, hipStre
         return launch3<4, 2, false>(p, grid, st);
     }
     if (p.k == 32) return launch3<32, 2, true>(p, grid, st);
+    if (p.k == 4) return launch3<4, 2, true>(p, grid, st);
     if (p.s == 1) return launch3<8, 1, true>(p, grid, st);
     return launch3<8, 2, true>(p, grid, st);
 }
