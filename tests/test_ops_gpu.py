@@ -51,6 +51,9 @@ GEOMS = [
     (False, 16, 250, 32, 2, 16, 64, 16), (False, 24, 250, 32, 2, 16, 66, 32), (True, 250, 16, 32, 2, 16, 33, 16),
     (False, 40, 250, 8, 1, 2, 34, 3), (False, 40, 250, 8, 2, 1, 125, 3), (False, 70, 250, 4, 2, 1, 62, 5), (True, 250, 24, 8, 2, 1, 31, 4),
     (False, 16, 250, 8, 1, 2, 35, 2),
+    # k = 5 at stride 2 on the one-wave-per-SIMD kernels (a virtual k = 8 whose virtual taps' MFMAs are never issued): forward and dgrad
+    # of both layer kinds with ~250 GEMM rows on the side that takes them
+    (True, 48, 125, 5, 2, 1, 30, 6), (False, 32, 250, 5, 2, 2, 61, 4), (False, 125, 40, 5, 2, 2, 61, 4), (True, 250, 40, 5, 2, 1, 30, 5),
 ]
 
 
@@ -390,7 +393,7 @@ def _random_geoms_one_wave(n, seed):
     out = []
     while len(out) < n:
         tr = bool(rs.randint(2))
-        k, s = [(32, 2), (8, 1), (8, 2), (4, 2)][rs.randint(4)]
+        k, s = [(32, 2), (8, 1), (8, 2), (4, 2), (5, 2)][rs.randint(5)]
         p = int(rs.randint(0, k))
         big, small = int(rs.choice([200, 236, 250, 256, 470, 500])), int(rs.choice([8, 16, 24, 32, 48]))
         # conv: rows of fwd = Cout, of dgrad (T form) = Cin * s; convT: rows of fwd (T form) = Cout * s, of dgrad = Cin

@@ -13,8 +13,8 @@
 // gaps carry the reads of the next slab's first fragments.
 //
 // Covered: fp32 operands (precision 0), F: k = 32 / 8 / 4 at stride 2 and k = 8 at stride 1; T: k = 32 / 8 / 4 at stride 2 (phase-major
-// weight image), k = 8 at stride 1; whole 16-deep slabs only (Cin a multiple of 16 / taps-per-channel).  Everything else -- k = 5,
-// the bf16 operand modes, K tails, small problems -- stays on conv_raw.hip / conv_raw_tall.hip / conv_im2col.hip.
+// weight image), k = 8 at stride 1, and k = 5 at stride 2 in both forms (a virtual k = 8); whole 16-deep slabs only (Cin a multiple of
+// 16 / taps-per-channel).  Everything else -- the bf16 operand modes, K tails, small problems -- stays on conv_raw.hip / conv_raw_tall.hip / conv_im2col.hip.
 #include "conv_common.h"
 
 namespace {
@@ -103,19 +103,28 @@ template <bool DESC, bool ACT, bool TJ2 = false> __device__ __forceinline__ void
         }
 }
 
+// k = 5 at stride 2 runs as a VIRTUAL k = 8 (conv_raw_impl.h): the weight tile is read as if every (row, channel) had 8 taps -- taps 5, 6, 7
+// are the next weight row's first floats -- and the MFMAs whose k positions hold a virtual tap in BOTH lane halves are never issued:
+// K5 = 2 (F form: tap = k index 0 ... 7 of the lane half): kk = 5, 6, 7; K5 = 1 (T form, phase-major rows: taps 2 jj + phi, jj = kk & 3):
+// phase 0: jj = 3, phase 1: jj = 2, 3.  MFMA work stays the algorithmic 5 / 8 of the virtual problem.
+template <int K5> __device__ __forceinline__ constexpr bool r3_k5_virtual(int i, int kk) {
+    return K5 == 1 ? ((i & 1) == 0 ? (kk & 3) == 3 : (kk & 3) >= 2) : (K5 == 2 ? kk >= 5 : false);
+}
+
 // One half-slab: the 64 MFMAs of `cur` (4 k x 8 row blocks x 2 column blocks) and in their gaps -- one piece per MFMA, pinned by
 // scheduling fences -- the reads of the NEXT half-slab's fragments `nxt` (window dwords behind MFMAs 0-3, weight rows behind 4-11),
 // gathers of the slab two ahead behind MFMAs 12, 16, ... 56 (`issue(E0 + n)`), the wait for the reads behind 60 and the activation
 // of the window values behind 61.
-template <int TJ, bool DESC, int RS, bool PM, bool ACT, int E0, typename Issue>
+template <int TJ, bool DESC, int RS, bool PM, bool ACT, int K5, int CC, int E0, typename Issue>
 __device__ __forceinline__ void r3_half(const R3Frag& cur, R3Frag& nxt, const float* nstage, int nc, int TA_, int r, int h,
                                         const int (&bbase)[2], float slope, AccT<8, 2>& acc, const Issue& issue) {
     const unsigned a0 = r3_a_addr<PM>(nstage, nc, r, h), a1 = PM ? r3_a_addr2<PM>(nstage, nc, r, h) : 0u;
     const unsigned b0 = r3_b_addr<TJ, DESC, RS>(nstage + TA_, nc, h, bbase[0]), b1 = r3_b_addr<TJ, DESC, RS>(nstage + TA_, nc, h, bbase[1]);
 #define R3_CHUNK(C, WORK)                                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                                           \
-    acc.c[((C) >> 1) & 7][(C) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r3_a_elem<PM>(cur, ((C) >> 1) & 7, (C) >> 4),          \
-                                                                         cur.b[(C) & 1][(C) >> 4], acc.c[((C) >> 1) & 7][(C) & 1], 0, 0, 0); \
+    if (!r3_k5_virtual<K5>(((C) >> 1) & 7, 4 * CC + ((C) >> 4)))         /* CC: which half of the slab `cur` is (k = 8 h + 4 CC + ..) */ \
+        acc.c[((C) >> 1) & 7][(C) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r3_a_elem<PM>(cur, ((C) >> 1) & 7, (C) >> 4),      \
+                                                                             cur.b[(C) & 1][(C) >> 4], acc.c[((C) >> 1) & 7][(C) & 1], 0, 0, 0); \
     WORK;
 #define R3_ROW(C0, W0, W1, W2, W3) R3_CHUNK(C0, W0) R3_CHUNK(C0 + 1, W1) R3_CHUNK(C0 + 2, W2) R3_CHUNK(C0 + 3, W3)
 #if defined(PG_R3_ABL) && (PG_R3_ABL == 4 || PG_R3_ABL == 5 || PG_R3_ABL == 7)
@@ -173,7 +182,10 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
     constexpr int TM = R3_TM, TN = R3_TN;
     constexpr int TA = TM * BK;                       // floats of the weight tile (16 KB)
     constexpr int AE16 = TM / 64;                     // 16-byte gather instructions per wave for the weight tile
-    constexpr int KWP = TKIND ? KW / S : KW;          // taps per channel in K order
+    constexpr int KWV = KW == 5 ? 8 : KW;             // taps per (row, channel) of the weight image: k = 5 is a virtual 8
+    constexpr int K5 = KW == 5 ? (TKIND ? 1 : 2) : 0;
+    constexpr int KWP = TKIND ? KWV / S : KWV;        // taps per channel in K order
+    static_assert(KW != 5 || S == 2, "k = 5 is built for stride 2 only");
     constexpr int TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ;
     constexpr int SC = TKIND ? 1 : S;
     constexpr int RG = raw_gap(TJ);
@@ -226,7 +238,8 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
                 avoff[e] = o < Mrows ? ((kc / KWP) * wq + o * KW + (kc % KWP)) * 4 : FAR;
             } else {
                 const int m = m0 + dma16_row(lane, wv, e);
-                avoff[e] = m < p.M ? (m * Ktot + dma16_kc(lane)) * 4 : FAR;
+                const int kc = dma16_kc(lane);      // k = 5: chunk kc = floats (kc & 7) .. + 3 of channel kc >> 3, rows 5 Q floats apart
+                avoff[e] = m < p.M ? (K5 ? (m * p.Q * 5 + (kc >> 3) * 5 + (kc & 7)) * 4 : (m * Ktot + kc) * 4) : FAR;
             }
         }
         // --- window gather offsets: thread owns window positions v = tid + 256 e (conv_raw_impl.h) --------------------------------
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
             const bool live = slab < se;
             const int k0 = slab * BK;
             if (e < AE16) {
-                const int sa = (PM || T16) ? (k0 / KWP) * wq * 4 : k0 * 4;
+                const int sa = (PM || T16) ? (k0 / KWP) * wq * 4 : (K5 ? (k0 >> 3) * 20 : k0 * 4);
                 dma16s(rw, stage + (4 * e + wv) * 256, live ? avoff[e < AE16 ? e : 0] : FAR, sa);
             } else if (e < ND) {
                 const int x = e - AE16, qi = x / NPC, pe0 = x - qi * NPC;
@@ -334,11 +347,11 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
             const int s2 = sl + 2;
             auto issue0 = [&](int e) { if (e < ND0) issue_piece(ring2, s2, e); };             // first half: gathers 0 ... ND0 - 1
             auto issue1 = [&](int e) { if (e < ND) issue_piece(ring2, s2, e); };              // second half: the rest (E0 = ND0)
-            r3_half<TJ, TKIND, RS, PM, ACT, 0>(f0, f1, cur, 1, TA, r, h, bbase, slopeB, acc, issue0);
+            r3_half<TJ, TKIND, RS, PM, ACT, K5, 0, 0>(f0, f1, cur, 1, TA, r, h, bbase, slopeB, acc, issue0);
             // (past the last slab of the segment the "next" stage holds zero-filled or older slabs: read, never multiplied; f0 is
             // carried by the loop, so its registers stay reserved until the reads have landed -- conv_h3.hip on dead asm reads)
             wait_next();
-            r3_half<TJ, TKIND, RS, PM, ACT, ND0>(f1, f0, lds + st1 * STG, 0, TA, r, h, bbase, slopeB, acc, issue1);
+            r3_half<TJ, TKIND, RS, PM, ACT, K5, 1, ND0>(f1, f0, lds + st1 * STG, 0, TA, r, h, bbase, slopeB, acc, issue1);
             st = st1;
         }
         __syncthreads();
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(NT3) void conv_raw3_fixup_kernel(const IgemmParams 
 
 template <int KW, int S, bool TK, bool ACT>
 hipError_t launch3a(const IgemmParams& p, int grid, hipStream_t st) {
-    constexpr int KWP = TK ? KW / S : KW, TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ, SC = TK ? 1 : S;
+    constexpr int KWV = KW == 5 ? 8 : KW, KWP = TK ? KWV / S : KWV, TJ = KWP < 16 ? KWP : 16, NQ = 16 / TJ, SC = TK ? 1 : S;
     constexpr int lds_bytes = R3_RING * (R3_TM * BK + NQ * (SC == 1 ? RS1 : RS2)) * 4;
     // (the attribute belongs to (function, current device): set on every call, nothing cached between calls)
     hipError_t e = hipFuncSetAttribute((const void*)conv_raw3_kernel<KW, S, TK, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -419,12 +432,13 @@ hipError_t launch3(const IgemmParams& p, int grid, hipStream_t st) {
 }  // namespace
 
 bool pgconv::raw3_covers(int kind, const IgemmParams& p) {
+    const bool k5 = p.k == 5 && p.s == 2;
     if (kind == KIND_F) {
-        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
+        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || k5)) return false;
     } else if (kind == KIND_T) {
-        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
+        if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || k5)) return false;
     } else return false;
-    const int kwp = kind == KIND_T ? p.k / p.s : p.k, tj = kwp < 16 ? kwp : 16;
+    const int kv = k5 ? 8 : p.k, kwp = kind == KIND_T ? kv / p.s : kv, tj = kwp < 16 ? kwp : 16;
     return ((long)p.Q * kwp) % BK == 0 && p.Q % (16 / tj > 0 ? 16 / tj : 1) == 0;     // whole slabs of whole channels only
 }
 
@@ -433,10 +447,12 @@ hipError_t pgconv::launch_raw3(int kind, const IgemmParams& p, int grid, hipStre
         if (p.k == 32) return launch3<32, 2, false>(p, grid, st);
         if (p.k == 8 && p.s == 1) return launch3<8, 1, false>(p, grid, st);
         if (p.k == 8) return launch3<8, 2, false>(p, grid, st);
+        if (p.k == 5) return launch3<5, 2, false>(p, grid, st);
         return launch3<4, 2, false>(p, grid, st);
     }
     if (p.k == 32) return launch3<32, 2, true>(p, grid, st);
     if (p.k == 4) return launch3<4, 2, true>(p, grid, st);
+    if (p.k == 5) return launch3<5, 2, true>(p, grid, st);
     if (p.s == 1) return launch3<8, 1, true>(p, grid, st);
     return launch3<8, 2, true>(p, grid, st);
 }
