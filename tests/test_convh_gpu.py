@@ -3,6 +3,7 @@ SAME bf16 operands (products of bf16 values are exact in fp32, so only the accum
 every (k, stride) geometry of the U-Net, at ragged sizes (partial tiles in M and N, several samples per tile, odd frame counts
 whose last bf16 pair is half padding) and under both work decompositions; plus the helper kernels (weight shadow, row cast,
 BatchNorm's bf16 outputs)."""
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -228,7 +229,7 @@ def test_conv_h3_is_race_free_by_repetition(geom):
     wh = ops.shadow_weights(w.cuda(), tr, s)
     for sched in (4096 | 2, 4096 | 1):
         first = None
-        for it in range(40):
+        for it in range(int(os.environ.get("PG_RACE_REPS", "40"))):       # (a one-off soak: PG_RACE_REPS=400)
             y = torch.empty(tuple(want.shape), device="cuda")
             ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y, schedule=sched)
             if first is None:
