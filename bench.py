@@ -54,6 +54,7 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 16 x the fp32 rate (v_mfma_f32_32x
 # operands -- the power management clocks the MFMA-dense loop down with the bits that toggle.  `roofline.peak` stays the data-sheet
 # figure; the bf16 lines also carry the fraction of this measured, power-limited rate.
 SUSTAINED_BF16_MFMA_TFLOPS_RANDOM = 1778.0
+PEAK_HBM_TBPS = 8.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s (about 6.3 TB/s is what a streaming kernel reaches)
 DTYPES = {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate",
           "bf16x3": "f32 operands split hi+lo into 3 bf16 MFMA products / f32 accumulate"}
 
@@ -66,6 +67,52 @@ def conv_flops(C, L, B):
     g = {"D0": (C, 2 * C, 32, L1), "D1": (2 * C, 2 * C, 8, L2), "D2": (2 * C, 2 * C, 8, L3), "D3": (2 * C, 4 * C, 4, L4),
          "U3": (4 * C, 2 * C, 5, L4), "U2": (4 * C, 2 * C, 8, L3), "U1": (4 * C, 2 * C, 8, L2), "U0": (4 * C, 2 * C, 32, L1)}
     return {n: 2.0 * B * pos * ci * co * k for n, (ci, co, k, pos) in g.items()}
+
+
+def device_info(torch, probe=True):
+    """Which box and which clocks a line was measured on (a 13 % spread between boxes on the power-limited bf16 pipe went
+    unexplained).  pci_bus / uuid identify the card; `mfma_probe` runs tools/dbg/mfma_peak.hip's register-only MFMA loops (no LDS, no
+    memory, every SIMD) for a few ms and reports what THIS chip sustains right now: TFLOP/s and the shader clock (s_memtime ticks per
+    s_memrealtime tick) for fp32 MFMA and for bf16 MFMA on random operands -- the power-limited ceiling of the bf16 path."""
+    import ctypes
+    p = torch.cuda.get_device_properties(torch.cuda.current_device())
+    out = {"name": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count,
+           "pci_bus": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0)),
+           "uuid": str(getattr(p, "uuid", "")), "host": os.uname().nodename}
+    so = os.path.join(ROOT, "tools", "dbg", "libmfma_peak.so")
+    if probe and os.path.exists(so):
+        try:
+            lib = ctypes.CDLL(so)
+            sig = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)] * 2
+            lib.mfma_peak.argtypes = lib.mfma_peak_f32.argtypes = sig
+            pr = {}
+            for name, fn, iters in (("bf16_random_operands", lib.mfma_peak, 100000), ("fp32_random_operands", lib.mfma_peak_f32, 50000)):
+                tf, mhz = ctypes.c_double(), ctypes.c_double()
+                rc = fn(2 * p.multi_processor_count, 256, iters, 3, 1, ctypes.byref(tf), ctypes.byref(mhz))
+                pr[name] = {"tflops": round(tf.value, 1), "shader_mhz": round(mhz.value), "rc": rc}
+            out["mfma_probe"] = pr
+        except Exception as e:          # noqa: BLE001
+            out["mfma_probe"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def conv_bytes(C, L, B, fused_adam=True):
+    """Algorithmic HBM bytes per launch of every conv pass (each operand once, fp32): fwd = x + w + y (+ the second activated copy
+    where the engine stores one), dgrad = dy + w + dx (+ skip gradient and mask tensor read), wgrad = x + dy + dw (+ 24 B per
+    parameter when the Adam update runs in its epilogue)."""
+    from phasegen.unet import frame_plan
+    L1, L2, L3, L4 = frame_plan(L)
+    g = {"D0": (C, 2 * C, 32, L, L1), "D1": (2 * C, 2 * C, 8, L1, L2), "D2": (2 * C, 2 * C, 8, L2, L3), "D3": (2 * C, 4 * C, 4, L3, L4),
+         "U3": (4 * C, 2 * C, 5, L4, L3), "U2": (4 * C, 2 * C, 8, L3, L2), "U1": (4 * C, 2 * C, 8, L2, L1), "U0": (4 * C, 2 * C, 32, L1, L)}
+    two_copies = {"D0"}                                   # D0 stores leaky(a0) and relu(a0); the others feed a BatchNorm
+    extra_reads = {"D3": 2, "D2": 2, "D1": 2, "U0": 1, "U1": 1, "U2": 1, "U3": 1}   # dgrad epilogue: skip gradient + mask tensor / mask tensor
+    out = {}
+    for n, (ci, co, k, li, lo) in g.items():
+        w, x, y = 4 * ci * co * k, 4 * B * ci * li, 4 * B * co * lo
+        out[n + ".fwd"] = w + x + y * (2 if n in two_copies else 1)
+        out[n + ".dgrad"] = w + y + x * (1 + extra_reads.get(n, 0))
+        out[n + ".wgrad"] = x + y + w + (6 * w if fused_adam else 0)
+    return out
 
 
 def host_threads():
@@ -146,7 +193,17 @@ def kernel_pass(torch, ops, step_fn, steps, fl, peak, step_ms):
     torch.cuda.synchronize()
     ops.set_timer(None)
     ks, by = {}, {}
+    hbm = {}
     for label, (n, ms) in sorted(timer.summary().items()):
+        if label.startswith("hbm:"):              # BatchNorm / loss / Adam: algorithmic bytes over the launch's event time
+            nb = timer.bytes.get(label, 0)
+            grp = label[4:].split(".")[0]
+            e = hbm.setdefault(grp, {"launches_per_step": 0, "ms_per_step": 0.0, "bytes_per_step": 0, "launches": {}})
+            e["launches_per_step"] += 1
+            e["ms_per_step"] += ms
+            e["bytes_per_step"] += nb
+            e["launches"][label[4:]] = {"ms": round(ms, 4), "bytes": nb, "TBps": round(nb / ms / 1e9, 3) if ms > 0 else None}
+            continue
         plan = timer.plans.get(label, "?")
         kern = plan.split("|")[0]
         f = fl[label.split(".")[0]]
@@ -162,19 +219,29 @@ def kernel_pass(torch, ops, step_fn, steps, fl, peak, step_ms):
         e["frac"] = round(e["tflops"] / peak, 4)
         e["share_of_step"] = round(e["ms_per_step"] / step_ms, 4)
         e["ms_per_step"] = round(e["ms_per_step"], 4)
+    for e in hbm.values():
+        e["TBps"] = round(e["bytes_per_step"] / e["ms_per_step"] / 1e9, 3) if e["ms_per_step"] > 0 else None
+        e["frac_of_hbm_peak"] = round(e["TBps"] / PEAK_HBM_TBPS, 4) if e["TBps"] else None
+        e["share_of_step"] = round(e["ms_per_step"] / step_ms, 4)
+        e["ms_per_step"] = round(e["ms_per_step"], 4)
+    kernel_pass.hbm = hbm         # (picked up by the caller right after the call)
     return ks, by
 
 
-def roofline_of(by, peak, step_tflops, precision, headline_shape):
+def roofline_of(by, peak, step_tflops, precision, headline_shape, alg_bytes=None):
     dom = max(by, key=lambda k: by[k]["ms_per_step"])
     big = {k: v for k, v in by.items() if v["share_of_step"] >= 0.003}
     worst = min(big, key=lambda k: big[k]["frac"])
     d = by[dom]
     traffic, src = pmc_traffic(dom) if headline_shape and precision == "fp32" else (None, None)
-    if headline_shape:        # HBM-side bytes per launch (L2 fills + write-backs) of the five largest kernels, from the committed counters
-        for k in sorted(by, key=lambda k: -by[k]["ms_per_step"])[:5]:
+    if headline_shape:        # HBM-side bytes per launch (L2 fills + write-backs) of EVERY kernel, from the committed counter passes,
+        for k in by:          # and their ratio to the algorithmic bytes of the launches the symbol covers (each operand once)
             t, tsrc = pmc_traffic(k)
             by[k]["traffic"], by[k]["traffic_source"] = t, tsrc
+            if alg_bytes is not None:
+                ab = sum(alg_bytes.get(l, 0) for l in by[k]["layers"]) / max(1, by[k]["launches_per_step"])
+                by[k]["algorithmic_bytes_per_launch"] = ab
+                by[k]["traffic_ratio"] = round(t / ab, 2) if (t and ab) else None
     return {"bound": "mfma", "kernel": dom + " (" + ", ".join(d["layers"]) + ")",
             "achieved": d["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE)", "traffic_source": src,
@@ -265,6 +332,7 @@ def run_train(a, torch, dist, world, rank, local):
     from phasegen.trainer import Trainer
     C, L, B = a.channels, a.frames, a.batch
     peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    dev = device_info(torch) if rank == 0 else None
     torch.manual_seed(0)
     model = UNetModel(C, 2 * C, gpu_ids=[local], precision=a.precision)
     selftest = a.dp_selftest and world == 1         # one-rank RCCL group: every collective of the N > 1 path is really issued
@@ -296,6 +364,7 @@ def run_train(a, torch, dist, world, rank, local):
     fl = conv_flops(C, L, B)
     step_flops = 3 * sum(fl.values()) - fl["D0"]
     ks, by = kernel_pass(torch, ops, lambda: trainer.step(batch), 3, fl, peak, step_ms)
+    hbm, hbm_mode = kernel_pass.hbm, "the timed step's own launches"
     plain = None
     if trainer.fuse_adam:
         # the wgrad launches above carry the Adam update of their weight (24 B of HBM traffic per parameter in the epilogue, not
@@ -303,6 +372,10 @@ def run_train(a, torch, dist, world, rank, local):
         trainer.fuse_adam = False
         trainer.step(batch)
         _, plain = kernel_pass(torch, ops, lambda: trainer.step(batch), 3, fl, peak, step_ms)
+        # the HBM-bound side of the step (BatchNorm, loss, Adam) is reported from THIS pass: with the update fused into the wgrad
+        # epilogues the headline step launches no Adam kernel for the conv weights at all; here it runs as per-layer slices on the side
+        # stream, beside backward's convolutions -- what a data-parallel rank executes
+        hbm, hbm_mode = kernel_pass.hbm, "pass with fuse_adam=False: Adam as per-layer slices on the side stream, beside backward's dgrad kernels"
         trainer.fuse_adam = True
     if rank != 0:
         return
@@ -318,8 +391,14 @@ def run_train(a, torch, dist, world, rank, local):
                    "adam": ("fused into the wgrad epilogues" if trainer.fuse_adam else
                             ("per-layer slices on a side stream" if trainer.overlap_adam else "one launch after backward")),
                    "final_loss": loss_val},
-        "roofline": roofline_of(by, peak, step_flops / (dt / a.steps) / 1e12, a.precision, (C, L, B) == (1024, 256, 64)),
+        "roofline": roofline_of(by, peak, step_flops / (dt / a.steps) / 1e12, a.precision, (C, L, B) == (1024, 256, 64),
+                                conv_bytes(C, L, B, trainer.fuse_adam)),
+        "hbm_kernels": {"bound": "hbm", "peak_TBps": PEAK_HBM_TBPS, "from": hbm_mode,
+                        "what": "algorithmic bytes (each operand once: BatchNorm forward 1 read + 1-2 writes, backward 2 reads + 1 write, "
+                                "loss 16 B in + 8 B out per bin-frame, Adam 28 B per parameter) / HIP-event time of the launch on its stream",
+                        "by_kernel": hbm},
         "kernels": ks,
+        "device": dev,
     }
     if plain is not None:
         dom = out["roofline"]["kernel"].split(" (")[0]
@@ -355,6 +434,7 @@ def run_train(a, torch, dist, world, rank, local):
         out["other_precisions"] = other
     if world == 1 and a.precision == "fp32" and not a.no_other_configs and (C, L, B) == (1024, 256, 64):
         out["other_configs"] = other_configs(torch, dist, model, C, L, B)      # (each leg catches its own failure)
+        out["projected_dp_efficiency_8gpu"] = projected_dp_efficiency(out)
     if world == 1 and not a.no_cpu_baseline and a.precision == "fp32":
         del trainer, model, batch
         torch.cuda.empty_cache()
@@ -417,6 +497,7 @@ def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf1
     U-Net forward (bf16-resident operands by default) -> ISTFT of (exp(m) - 1) e^{j phi}.  No exchange step: ranks are replicas."""
     from phasegen import audio, ops
     n_fft, hop, n = 2048, 512, 255 * 512
+    dev = device_info(torch) if rank == 0 else None
     peak = PEAK_FP32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
     C = n_fft // 2
     nsig, frames = 2 * clips, 1 + n // hop
@@ -467,6 +548,18 @@ def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf1
                             "by_kernel holds per-launch event times (an event pair per launch reads a few % longer than the clean loop)")
     dom = roof["kernel"].split(" (")[0]
     roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
+    # HBM-side stages.  Algorithmic bytes per frame: STFT 2048/512 reads hop samples
+    # (2 KB) and writes 1024 bins x [re; im] or [log1p|z|; angle] (8 KB); the ISTFT reads 8 KB and writes 2 KB (+ 2 x 2 KB for the
+    # peak normalisation's read-modify-write, which the algorithm needs: the peak is known only after the last sample).
+    def stage(ms, nbytes, kernels):
+        t = [pmc_traffic(k) for k in kernels]
+        tr = sum(v for v, _ in t if v) if all(v for v, _ in t) else None
+        return {"ms": round(ms, 4), "algorithmic_bytes": nbytes, "TBps": round(nbytes / ms / 1e9, 3), "frac": round(nbytes / ms / 1e9 / PEAK_HBM_TBPS, 4),
+                "bound": "hbm", "peak_TBps": PEAK_HBM_TBPS, "traffic": tr, "traffic_ratio": round(tr / nbytes, 2) if tr else None,
+                "traffic_source": t[0][1], "kernels": kernels}
+    nf = nsig * frames
+    stage_roofline = {"stft+polar": stage(stage[0] / 3, nf * (hop * 4 + n_fft * 4), ["stft_frames_kernel<false>"]),
+                      "istft": stage(stage[2] / 3, nf * (n_fft * 4 + hop * 4 + 2 * hop * 4), ["istft_fused_kernel", "istft_peak_normalize_kernel"])}
     return {
         "metric": "spectrogram-frames/sec end to end (STFT + U-Net forward + ISTFT)", "value": world * nsig * frames / sec,
         "unit": "frames/s", "clips_per_s": world * clips / sec, "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -476,20 +569,54 @@ def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf1
                                f"STFT+polar -> UNetModel({C}, {2 * C}).forward -> ISTFT", "signals_per_rank": nsig, "frames": frames},
         "stage_ms": {"stft+polar": stage[0] / 3, "unet_forward": fwd_ms, "istft": stage[2] / 3,
                      "unet_forward_event_bracketed": stage[1] / 3, "unet_forward_graph_replay": graph_ms},
-        "roofline": roof, "kernels": ks}
+        "stage_roofline": stage_roofline, "roofline": roof, "kernels": ks, "device": dev}
 
 
-def measure_train(torch, model, B, C, L, seed, fuse_adam, warmup, steps):
-    """A full train.py:41-62 step at another shape / update placement on the SAME model (N = 1): ms and frames/s only."""
+def measure_train(torch, model, B, C, L, seed, fuse_adam, warmup, steps, contended=False, held=0):
+    """A full train.py:41-62 step at another shape / update placement on the SAME model (N = 1): ms and frames/s only.
+    ``contended``: backward's convolutions take the work split a data-parallel rank uses (engine.contended, set by the Trainer when
+    world > 1).  ``held``: the steps run while a collective-shaped kernel (tools/spin/spin.hip: 256 threads, 113 VGPRs, 32 KB LDS per
+    workgroup) holds that many CUs from a side stream, as RCCL's kernels do during a data-parallel backward."""
     from phasegen.trainer import Trainer
     trainer = Trainer(model, lr=1e-3, fuse_adam=fuse_adam)
     batch = synthetic_batch(torch, B, C, L, seed)
-    sec = _timed(torch, None, 1, lambda: trainer.step(batch), warmup, steps)
+    eng = model.engine
+    old = eng.contended
+    eng.contended = bool(contended)
+    info = None
+    try:
+        if not held:
+            sec = _timed(torch, None, 1, lambda: trainer.step(batch), warmup, steps)
+        else:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from hold import Hold
+            for _ in range(warmup):
+                trainer.step(batch)
+            torch.cuda.synchronize()
+            main = torch.cuda.current_stream()
+            hold = Hold()
+            hold.start(held, shape="rccl", max_us=int(1e6 * (2.0 + steps * 0.4)))
+            try:                        # nothing below may wait for the DEVICE (that would wait for the hold kernel): the main stream only
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    trainer.step(batch)
+                main.synchronize()      # (Trainer.step ends with the main stream waiting for its side stream)
+                sec = (time.perf_counter() - t0) / steps
+            finally:
+                info = hold.stop()
+            if info["held_ms_min"] < sec * steps * 1e3 * 0.98:
+                info["warning"] = "the hold kernel left before the timed steps ended"
+    finally:
+        eng.contended = old
     fl = conv_flops(C, L, B)
     tf = (3 * sum(fl.values()) - fl["D0"]) / sec / 1e12
-    return {"ms_per_step": sec * 1e3, "frames_per_s": B * L / sec, "steps": steps, "warmup": warmup, "batch": B, "frames": L,
-            "channels": C, "step_tflops": round(tf, 2), "step_frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-            "adam": "fused into the wgrad epilogues" if trainer.fuse_adam else "per-layer slices on a side stream"}
+    out = {"ms_per_step": sec * 1e3, "frames_per_s": B * L / sec, "steps": steps, "warmup": warmup, "batch": B, "frames": L,
+           "channels": C, "step_tflops": round(tf, 2), "step_frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+           "adam": "fused into the wgrad epilogues" if trainer.fuse_adam else "per-layer slices on a side stream",
+           "work_split": "contended (data-parallel policy)" if contended else "automatic"}
+    if info is not None:
+        out["hold"] = info
+    return out
 
 
 def other_configs(torch, dist, model, C, L, B):
@@ -517,15 +644,31 @@ def other_configs(torch, dist, model, C, L, B):
             e = measure_e2e(torch, dist, 1, 0, model, 32, 3, 10)
         finally:
             model.engine.precision = old
-        return {k: e[k] for k in ("metric", "value", "unit", "clips_per_s", "ms_per_step", "dtype", "config", "stage_ms", "roofline")}
+        return {k: e[k] for k in ("metric", "value", "unit", "clips_per_s", "ms_per_step", "dtype", "config", "stage_ms", "stage_roofline",
+                                  "roofline", "device")}
 
-    leg("dp_equivalent", lambda: dict(measure_train(torch, model, B, C, L, 1, False, 2, 5),
-                                      note="the headline step with fuse_adam=False: what every rank of an N > 1 run executes"))
+    leg("dp_equivalent", lambda: dict(measure_train(torch, model, B, C, L, 1, False, 2, 5, contended=True),
+                                      note="the headline step as every rank of an N > 1 run executes it: Adam NOT fused into the wgrad epilogues "
+                                           "(per-layer slices on a side stream) and engine.contended = True (the data-parallel work split)"))
+    leg("dp_equivalent_held32", lambda: dict(measure_train(torch, model, B, C, L, 1, False, 2, 5, contended=True, held=32),
+                                             note="the same step while a collective-shaped kernel holds 32 CUs (tools/contention.py, "
+                                                  "profiles/r04_contention.json): a one-GPU stand-in for RCCL's share of the chip"))
     leg("ref_default", lambda: dict(measure_train(torch, model, 16, C, 128, 3, True, 2, 10),
                                     note="the reference's own defaults, train.py:14-15: batch 16, 1024 bins x 128 frames"))
     leg("fwd", fwd)
     leg("e2e", e2e)
     return out
+
+
+def projected_dp_efficiency(out):
+    """dp_equivalent_held32 / headline: what one GPU can say about the N > 1 step (no multi-GPU node is reachable from the builder)."""
+    oc = out.get("other_configs", {})
+    h = oc.get("dp_equivalent_held32", {})
+    if "frames_per_s" in h:
+        return {"value": round(h["frames_per_s"] / out["value"], 4),
+                "what": "frames/s of the data-parallel step (side-stream Adam, contended split) beside a collective-shaped kernel on 32 CUs "
+                        "/ frames/s of the headline step; excludes the wire time of the 2.45 GB all-reduce itself (DESIGN.md section 4.5)"}
+    return None
 
 
 def run_fwd(a, torch, dist, world, rank, local):

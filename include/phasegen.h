@@ -24,7 +24,11 @@
 extern "C" {
 #endif
 
-#define PG_VERSION 300 /* 0.3.0: pg_conv_fwd_h reads its zero padding from the rows' tails and a PG_H_HEAD zero head (0.2.0: knobs in the argument structs) */
+#define PG_VERSION 400 /* 0.4.0: pg_bn_args.num_batches_tracked; (0.3.0: pg_conv_fwd_h reads its zero padding from the rows' tails and a
+                        * PG_H_HEAD zero head; 0.2.0: knobs in the argument structs).  Argument structs GROW between minor versions
+                        * (new fields are appended, and a zero / NULL there means the old behaviour), so their SIZE is part of the ABI:
+                        * a caller compiled against an older header passes a shorter struct and the library would read past its end.
+                        * Callers check pg_version() / 100 == PG_VERSION / 100 at load time and are rebuilt when it differs. */
 
 enum { PG_OK = 0, PG_ERR_NULL = -1, PG_ERR_SHAPE = -2, PG_ERR_ALIGN = -3, PG_ERR_UNSUPPORTED = -4,
        PG_ERR_WORKSPACE = -5 };
@@ -153,6 +157,7 @@ typedef struct pg_bn_args {
     /* y may then be NULL                                                                                               */
     uint16_t* yh;  int64_t yh_bs;  int32_t yh_pitch;  int32_t yh_act;
     uint16_t* yh2; int64_t yh2_bs; int32_t yh2_pitch; int32_t yh2_act;
+    int64_t* num_batches_tracked;        /* fwd, optional (NULL): the layer's nn.BatchNorm counter, incremented by one on the device */
 } pg_bn_args;
 int pg_bn_fwd(const pg_bn_args* a, void* stream);
 int pg_bn_bwd(const pg_bn_args* a, void* stream);

@@ -102,6 +102,25 @@ def test_unsupported_geometries_are_refused():
         ops.conv_fwd_h(x2, 24, torch.zeros(16 * 3 * 8, device="cuda", dtype=torch.bfloat16), (16, 3, 8), 1, 2, yh=ops.h_alloc(1, 16, 21, "cuda"))
 
 
+def test_activation_without_the_zero_head_is_refused():
+    """ABI 0.3 contract: the kernels read PG_H_HEAD zero elements in front of x.  A tensor that sits at the very start of its
+    allocation (plain torch.zeros instead of ops.h_alloc) must be refused on the host -- the C side cannot see it."""
+    from phasegen import ops
+    B, Cin, Cout, k, s, p, Lin = 1, 8, 16, 32, 2, 16, 24
+    w = rnd(3, Cout, Cin, k)
+    wh = ops.shadow_weights(w.cuda(), False, s)
+    Lout = ops.conv_out_len(Lin, k, s, p)
+    y = torch.empty(B, Cout, Lout, device="cuda")
+    plain = torch.zeros(B, Cin, ops.h_pitch(Lin), device="cuda", dtype=torch.bfloat16)      # right pitch and tails, NO head
+    with pytest.raises(ValueError, match="h_alloc"):
+        ops.conv_fwd_h(plain, Lin, wh, tuple(w.shape), s, p, y=y)
+    good = ops.h_alloc(B, Cin, Lin, "cuda")
+    ops.conv_fwd_h(good, Lin, wh, tuple(w.shape), s, p, y=y)                                  # same call with the head: accepted
+    cat = ops.h_alloc(B, 2 * Cin, Lin, "cuda")
+    ops.conv_fwd_h(cat[:, Cin:], Lin, wh, tuple(w.shape), s, p, y=y)                          # a channel slice has the previous row's tail
+    torch.cuda.synchronize()
+
+
 def test_bn_fwd_bf16_outputs():
     from phasegen import ops
     B, Cc, L = 5, 24, 61

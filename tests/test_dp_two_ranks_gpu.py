@@ -118,7 +118,8 @@ def val_worker(rank, port, q):
         model = UNetModel(C, 2 * C).load_numpy(detgen.make_params(C, seed=0))
         vb = val_batch().cuda()
         got = validation_metrics(model, vb, hop_length=8, n_fft=2 * C, gl_iters=3, gl_seed=5, shard=True)
-        q.put((rank, got))
+        bufs = {k: v.cpu().numpy().tolist() for k, v in sorted(model.engine.arena.buffers.items())}
+        q.put((rank, (got, bufs)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -151,6 +152,10 @@ def test_sharded_validation_equals_single_process():
         assert p.exitcode == 0
     model = UNetModel(C, 2 * C).load_numpy(detgen.make_params(C, seed=0))
     want = validation_metrics(model, val_batch().cuda(), hop_length=8, n_fft=2 * C, gl_iters=3, gl_seed=5)
-    assert got[0] == got[1]
+    assert got[0][0] == got[1][0]
     for k in ("MSE", "NOPMSE", "LMSE"):
-        assert abs(got[0][k] - want[k]) < 1e-6 * abs(want[k]), (k, got[0][k], want[k])
+        assert abs(got[0][0][k] - want[k]) < 1e-6 * abs(want[k]), (k, got[0][0][k], want[k])
+    # the train-mode forwards of validation update the BatchNorm buffers with each rank's own clips (3 on rank 0, 2 on rank 1):
+    # rank 0's are broadcast afterwards, so the replicas stay identical -- and they are rank 0's three updates
+    assert got[0][1] == got[1][1], "BatchNorm buffers diverged between the ranks during sharded validation"
+    assert all(v == 3 for k, v in got[0][1].items() if k.endswith("num_batches_tracked"))

@@ -147,7 +147,10 @@ def test_resident_forward_graph_replay_equals_eager(B, L, update):
     eng.graphs = True
     got = [eng.forward(x, update_stats=update, inference=True).clone() for x in xs]       # eager, capture + replay, replay, replay
     assert all(torch.equal(g, w) for g, w in zip(got, want))
-    assert isinstance(eng.plans[("graph", B, L, update)], torch.cuda.CUDAGraph)
+    from phasegen import ops
+    graph, held_ws = eng.plans[("graph", B, L, update, ops.current_schedule(), eng.precision)]     # key = everything a capture freezes
+    assert isinstance(graph, torch.cuda.CUDAGraph) and held_ws.numel() > 0                          # the workspace lives with the graph
+    ops.release_workspaces()                                   #  dropping the caches must not pull memory from under the graph
     assert int(eng.arena.buffers[detgen.BN_KEYS[0] + ".num_batches_tracked"]) == nb0 + (4 if update else 0)
     with torch.no_grad():
         next(iter(m.parameters())).mul_(0.5)                   # new weights: the replay must see the rebuilt shadows

@@ -94,6 +94,59 @@ def test_istft_vs_oracle(bins, frames, hop, nsig):
             assert relmax(y[i], w) < 2e-5
 
 
+def test_polar_arithmetic_against_float64():
+    """pg_fastmath.h (round 4): |z| by scaled squares, log1p through v_log_f32 with the rounding of 1 + x divided out, atan2 as one
+    v_rcp_f32 + a 9-term odd polynomial.  Against float64 over 60 decades of magnitude, all four quadrants, both axes, signed zeros."""
+    from phasegen import ops
+    rng = np.random.default_rng(7)
+    n = 1 << 16
+    mag = 10.0 ** rng.uniform(-30, 30, n)
+    ang = rng.uniform(-np.pi, np.pi, n)
+    re, im = (mag * np.cos(ang)).astype(np.float32), (mag * np.sin(ang)).astype(np.float32)
+    # moderate magnitudes (what an STFT holds), the axes, signed zeros, ties |re| == |im|
+    m2 = 10.0 ** rng.uniform(-4, 4, n)
+    re2, im2 = (m2 * np.cos(ang)).astype(np.float32), (m2 * np.sin(ang)).astype(np.float32)
+    special = np.array([(0, 0), (-0.0, 0), (0, -0.0), (-0.0, -0.0), (1, 0), (-1, 0), (0, 1), (0, -1), (-1, -0.0), (1, -0.0), (3, 3), (-3, 3),
+                        (-3, -3), (3, -3), (1e-38, 1e-38), (-1e-40, 1e-40), (1e38, -1e38), (2.5, 1e-30), (-2.5, 1e-30), (1e-30, 2.5)], np.float32)
+    re = np.concatenate([re, re2, special[:, 0]])
+    im = np.concatenate([im, im2, special[:, 1]])
+    pad = (-len(re)) % 8
+    re, im = np.concatenate([re, np.ones(pad, np.float32)]), np.concatenate([im, np.ones(pad, np.float32)])
+    d = np.stack([re, im])[None, :, None, :]                                    # (1, 2, 1, n)
+    out = ops.polar(torch.from_numpy(np.ascontiguousarray(d)).cuda()).cpu().numpy()[0, :, 0]
+    z = d[0, 0, 0] + d[0, 1, 0] * 1j                 # data.py:40's own arithmetic, complex64 (an imaginary part of -0.0 becomes +0.0)
+    want_ang = np.angle(z.astype(np.complex128))
+    want_mag = np.log1p(np.abs(z.astype(np.complex128)))
+    finite = np.isfinite(want_mag)
+    assert np.max(np.abs(out[1] - want_ang)) < 5e-7
+    rel = np.abs(out[0][finite] - want_mag[finite]) / np.maximum(want_mag[finite], 1e-37)
+    assert np.max(rel) < 6e-7, float(np.max(rel))
+    k = len(special)
+    sp = out[1][2 * n:2 * n + k]
+    assert sp[0] == 0.0 and sp[1] == np.float32(np.pi) and sp[4] == 0.0 and sp[5] == np.float32(np.pi)   # origin, -0 real axis, axes exact
+    assert sp[6] == np.float32(np.pi / 2) and sp[7] == np.float32(-np.pi / 2)
+
+
+@pytest.mark.parametrize("bins,frames,hop,nsig", [(1024, 256, 512, 3), (512, 64, 256, 2), (64, 37, 32, 2)])
+def test_istft_synthesis_arithmetic_and_fused_path(bins, frames, hop, nsig):
+    """(1) mode 0 = (exp(m) - 1) e^{j phi} on v_exp_f32 and the polynomial sincos (pg_fastmath.h) equals mode 1 fed the same
+    spectrum formed in float64; (2) the fused kernel (frames + overlap-add + peaks in one launch, ranges with halo groups and flush
+    groups) equals the one-frame-per-workgroup schedule, which still runs the three-kernel path."""
+    from phasegen import ops
+    m = np.abs(detgen.normal(41, (nsig, bins, frames))).astype(np.float32) * 2.0
+    phi = (detgen.normal(42, (nsig, bins, frames)) * 4.0).astype(np.float32)          # beyond (-pi, pi]: the network's output is unbounded
+    zr = (np.expm1(m.astype(np.float64)) * np.cos(phi.astype(np.float64))).astype(np.float32)
+    zi = (np.expm1(m.astype(np.float64)) * np.sin(phi.astype(np.float64))).astype(np.float32)
+    for norm in (False, True):
+        y0 = ops.istft(torch.from_numpy(m).cuda(), torch.from_numpy(phi).cuda(), hop, mode=0, normalize=norm).cpu().numpy()
+        y1 = ops.istft(torch.from_numpy(zr).cuda(), torch.from_numpy(zi).cuda(), hop, mode=1, normalize=norm).cpu().numpy()
+        assert relmax(y0, y1) < 1e-5
+        y2 = ops.istft(torch.from_numpy(zr).cuda(), torch.from_numpy(zi).cuda(), hop, mode=1, normalize=norm, single_frame=True).cpu().numpy()
+        assert relmax(y1, y2) < 1e-5
+        if norm:
+            assert np.allclose(np.abs(y1).max(axis=1), 1.0, atol=1e-6)
+
+
 @pytest.mark.parametrize("n,n_fft,hop,nsig", [(66100, 2048, 512, 3), (10007, 512, 128, 2), (3001, 256, 50, 1), (97, 32, 8, 5)])
 def test_batched_and_single_frame_transforms_agree(n, n_fft, hop, nsig):
     """The two transform schedules (4 frames per workgroup through the half-length radix-4 real FFT / one frame per

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include "phasegen.h"
 #include "pg_common.h"
+#include "pg_fastmath.h"
 
 namespace {
 
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const pg_bn_args a) {
             const float unbiased = var * ((float)n / (float)(n > 1 ? n - 1 : 1));
             a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unbiased;
         }
+        if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;       // nn.BatchNorm's counter: no separate launch for it
     }
 }
 
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256) void bn_fwd_reg_kernel(const pg_bn_args a) {
             const float unbiased = var * ((float)n / (float)(n > 1 ? n - 1 : 1));
             a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unbiased;
         }
+        if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;       // nn.BatchNorm's counter: no separate launch for it
     }
 }
 
@@ -376,12 +379,8 @@ void adam_thin_kernel(float* __restrict__ p, const float* __restrict__ g, float*
 // ---------------------------------------------------------------------------------------------------------
 // data.py:39-47: [re; im] -> [log1p(|z|); angle(z)], 16 B of traffic per bin-frame.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void polar_one(float re, float im, int use_exp, float& mag, float& ang) {
-    pg_complex_from_parts(re, im);
-    const float m = hypotf(re, im);
-    mag = use_exp ? log1pf(m) : m;
-    ang = atan2f(im, re);
-}
+// (the arithmetic is pg_polar_one, pg_fastmath.h: shared with the STFT kernel's fused epilogue, so the two stay bit-identical)
+__device__ __forceinline__ void polar_one(float re, float im, int use_exp, float& mag, float& ang) { pg_polar_one(re, im, use_exp, mag, ang); }
 
 // VEC = 4: 16-B loads/stores (inner % 4 == 0 and 16-B aligned planes); VEC = 1: any shape
 template <int VEC>

@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include "phasegen.h"
 #include "pg_common.h"
+#include "pg_fastmath.h"
 
 #ifndef PG_STFT_ABL
 #define PG_STFT_ABL 0
@@ -93,9 +94,10 @@ __global__ __launch_bounds__(FFT_THREADS) void stft_kernel(const pg_stft_args a)
     for (int k = 1 + threadIdx.x; k <= bins; k += blockDim.x) {      // bin 0 (DC) dropped, preproc_mdb.py:93
         float2 v = X[k];
         if (a.polar) {
-            pg_complex_from_parts(v.x, v.y);
-            o_re[(long)(k - 1) * a.n_frames] = log1pf(hypotf(v.x, v.y));
-            o_im[(long)(k - 1) * a.n_frames] = atan2f(v.y, v.x);
+            float mg, an;
+            pg_polar_one(v.x, v.y, 1, mg, an);
+            o_re[(long)(k - 1) * a.n_frames] = mg;
+            o_im[(long)(k - 1) * a.n_frames] = an;
         } else {
             o_re[(long)(k - 1) * a.n_frames] = v.x;
             o_im[(long)(k - 1) * a.n_frames] = v.y;
@@ -205,10 +207,8 @@ __device__ __forceinline__ void stft_store_row(const pg_stft_args& a, float* o_r
     if (a.polar) {
 #pragma unroll
         for (int f = 0; f < SF; ++f) {
-            float r = re[f], i = im[f];
-            pg_complex_from_parts(r, i);
-            re[f] = log1pf(hypotf(r, i));
-            im[f] = atan2f(i, r);
+            const float r = re[f], i = im[f];
+            pg_polar_one(r, i, 1, re[f], im[f]);
         }
     }
     float* pr = o_re + row * a.n_frames;
@@ -359,9 +359,9 @@ __device__ __forceinline__ void istft_row(const pg_istft_args& a, const float* p
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
         if (a.mode == 0) {                                                // demo.py:39: (exp(m) - 1) e^{j phi}
-            const float mag = expf(va[f]) - 1.0f;
+            const float mag = pg_expm1_ref(va[f]);
             float s, c;
-            sincosf(vb[f], &s, &c);
+            pg_sincos(vb[f], s, c);
             X[f] = make_float2(mag * c, mag * s);
         } else X[f] = make_float2(va[f], vb[f]);
     }
@@ -437,6 +437,215 @@ __global__ __launch_bounds__(BT) void istft_frames4_kernel(const pg_istft_args a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused ISTFT (round 4): inverse frames, windowing, overlap-add, window-sum-square division, n_fft/2 trim and the per-workgroup
+// peak in ONE kernel -- the frame workspace (written, re-read: 2 x 134 MB at 64 x 256 frames of 2048 points) is gone.
+// A workgroup owns a RANGE of consecutive frame groups of one signal and walks them in order.  Per group (SF frames): spectrum rows
+// -> Hermitian half-length input -> radix-4 passes (as istft_frames4_kernel) -> the windowed real frames go to the ping-pong buffer
+// the transform does not end in (F, SF x n_fft floats) -> every output position the group completes, [t0 hop, (t0 + SF) hop), is the
+// sum of a CARRY (partial sums left by earlier frames, n_fft - hop floats of LDS) and the group's frames, read as 16 B pieces ->
+// divided by the analytic window-sum-square and stored once, 16 B per lane, coalesced; the group's tails become the next carry.
+// A range that does not start at frame 0 first runs the group in front of it for its carry only (the halo: n_fft <= (SF + 1) hop
+// guarantees one group suffices), and groups past the last frame flush the carry.  Needs hop % 4 == 0 and n_fft <= (SF + 1) hop;
+// other shapes keep the three-kernel path below.
+constexpr int CARRY_IT = 2;              // (n_fft - hop) / 4 float4 <= 2 x BT for n_fft <= 2048
+
+struct IstftPlan { int fused, rg, nranges, gs; };
+__host__ __device__ inline IstftPlan istft_plan(int n_signals, int bins, int n_frames, int hop, int single_frame, int cus) {
+    IstftPlan pl = {0, 0, 0, 0};
+    const int N = 2 * bins;
+    if (single_frame || N > 2 * MAX_HALF || (hop & 3) || N > (SF + 1) * hop || hop > N || (N - hop) > 4 * CARRY_IT * BT || n_frames < 2) return pl;
+    const long padded = (long)(N >> 1) + (long)hop * (n_frames - 1);              // positions [0, padded) hold every trimmed output
+    pl.gs = (int)((padded + (long)SF * hop - 1) / ((long)SF * hop));               // groups that complete them (the last ones flush)
+    const int fg = (n_frames + SF - 1) / SF;                                      // groups that hold frames
+    int rg = (int)(((long)n_signals * fg) / (2L * cus));                          // aim at two workgroups per CU ...
+    rg = rg < 2 ? 2 : (rg > 8 ? 8 : rg);                                          // ... with 2..8 groups each (halo: one extra group)
+    pl.rg = rg;
+    pl.nranges = fg / rg < 1 ? 1 : fg / rg;                                       // the last range takes the remainder and the flush
+    pl.fused = 1;
+    return pl;
+}
+
+__global__ __launch_bounds__(BT) void istft_fused_kernel(const pg_istft_args a, float* partial, const IstftPlan pl) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    __shared__ float red[BT / 64];
+    const int M = a.bins, N = 2 * M, hop = a.hop;
+    float2* x = smem; float2* y = smem + SF * M; float2* tw = smem + 2 * SF * M;
+    float* carry = (float*)(tw + 3 * tw_len(M));
+    const int NC = N - hop;                                   // carry length
+    // workgroup -> (signal, range): consecutive ranges of a signal sit behind the same L2 (workgroups are dealt round-robin over XCDs)
+    const int total = a.n_signals * pl.nranges, chunk = (total + 7) >> 3, xcd = blockIdx.x & 7;
+    const int id = xcd * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || id >= total) return;
+    const int sig = id / pl.nranges, rng = id - sig * pl.nranges;
+    const int g_begin = rng * pl.rg, g_end = rng == pl.nranges - 1 ? pl.gs : (rng + 1) * pl.rg;
+    const int len = hop * (a.n_frames - 1);
+    fill_tw4(tw, M, 1.f);
+    float w0[M_ITERS], w1[M_ITERS], sc[K_ITERS], ss[K_ITERS];
+    const float inv = 1.0f / (float)M;
+#pragma unroll
+    for (int i = 0; i < M_ITERS; ++i) {
+        const int m = threadIdx.x + i * BT;
+        w0[i] = inv * hann(2 * m, N); w1[i] = inv * hann(2 * m + 1, N);
+    }
+#pragma unroll
+    for (int i = 0; i < K_ITERS; ++i)
+        sincospif((float)(1 + threadIdx.x + i * BT) / (float)M, &ss[i], &sc[i]);    // exp(+2 pi i k / n_fft)
+    for (int j = threadIdx.x; j < NC; j += BT) carry[j] = 0.f;
+    const bool vec4 = (a.n_frames & 3) == 0 && ((a.a_bs | a.b_bs) & 3) == 0 && ((((uintptr_t)a.a) | ((uintptr_t)a.b)) & 15) == 0;
+    float sd, cd, sh, ch;                                     // window rotations: one sample, one hop
+    sincospif(2.0f / (float)N, &sd, &cd);
+    sincospif(2.0f * (float)hop / (float)N, &sh, &ch);
+    float* out = a.audio + (long)sig * len;
+    float mx = 0.f;
+    __syncthreads();
+    for (int g = g_begin > 0 ? g_begin - 1 : 0; g < g_end; ++g) {
+        const bool halo = g < g_begin;
+        const int t0 = g * SF;
+        const int nfr = a.n_frames - t0 < 0 ? 0 : (a.n_frames - t0 > SF ? SF : a.n_frames - t0);
+        const float* F = nullptr;                             // SF windowed frames of n_fft floats; nullptr: no frame left (flush)
+        if (nfr > 0) {
+            const float* pa = a.a + (long)sig * a.a_bs + t0;
+            const float* pb = a.b + (long)sig * a.b_bs + t0;
+            const bool vec = vec4 && nfr == SF;
+#pragma unroll
+            for (int i = 0; i < K_ITERS; ++i) {               // Z[k] = E[k] + i O[k] (see istft_frames4_kernel)
+                const int k = 1 + threadIdx.x + i * BT;
+                if (k <= (M >> 1)) {
+                    const int ea = swz(k), eb = swz(M - k);
+                    float2 Xk[SF], Xm[SF];
+                    istft_row(a, pa, pb, k, nfr, vec, Xk);
+                    istft_row(a, pa, pb, M - k, nfr, vec, Xm);
+#pragma unroll
+                    for (int f = 0; f < SF; ++f) {
+                        const float2 E = make_float2(0.5f * (Xk[f].x + Xm[f].x), 0.5f * (Xk[f].y - Xm[f].y));
+                        const float2 D = make_float2(0.5f * (Xk[f].x - Xm[f].x), 0.5f * (Xk[f].y + Xm[f].y));
+                        const float2 O = cmul(D, make_float2(sc[i], ss[i]));
+                        x[f * M + ea] = make_float2(E.x - O.y, E.y + O.x);
+                        if (k != M - k) x[f * M + eb] = make_float2(E.x + O.y, O.x - E.y);
+                    }
+                }
+            }
+            if (threadIdx.x == 0) {
+                float2 Xn[SF];
+                istft_row(a, pa, pb, M, nfr, vec, Xn);
+#pragma unroll
+                for (int f = 0; f < SF; ++f) x[f * M] = make_float2(0.5f * Xn[f].x, -0.5f * Xn[f].x);
+            }
+            __syncthreads();
+            const float2* z = fft_frames<-1>(x, y, tw, M);
+            float2* Fw = (z == x) ? y : x;
+#pragma unroll
+            for (int i = 0; i < M_ITERS; ++i) {
+                const int m = threadIdx.x + i * BT;
+                if (m < M) {
+                    const int e = swz(m);
+#pragma unroll
+                    for (int f = 0; f < SF; ++f) {            // frames past the end were built from zero rows: they hold zeros
+                        const float2 v = z[f * M + e];
+                        Fw[f * M + m] = make_float2(v.x * w0[i], v.y * w1[i]);
+                    }
+                }
+            }
+            F = (const float*)Fw;
+            __syncthreads();
+        }
+        // the next carry: positions (t0 + SF) hop + j, j < n_fft - hop, as far as this group's frames reach them
+        float4 nc[CARRY_IT];
+#pragma unroll
+        for (int it = 0; it < CARRY_IT; ++it) {
+            nc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int j = 4 * (threadIdx.x + it * BT);
+            if (F && j < NC) {
+#pragma unroll
+                for (int f = 0; f < SF; ++f) {
+                    const int n = (SF - f) * hop + j;
+                    if (n < N) { const float4 v = *(const float4*)(F + f * N + n); nc[it].x += v.x; nc[it].y += v.y; nc[it].z += v.z; nc[it].w += v.w; }
+                }
+            }
+        }
+        if (!halo) {
+            for (int pr = 4 * threadIdx.x; pr < SF * hop; pr += 4 * BT) {          // positions t0 hop + pr .. + 3 (padded coordinates)
+                const int ip = t0 * hop + pr, i0 = ip - (N >> 1);
+                if (i0 < 0 || i0 >= len) continue;                                   // trimmed away (len, n_fft / 2, hop: multiples of 4)
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pr < NC) acc = *(const float4*)(carry + pr);
+                if (F) {
+#pragma unroll
+                    for (int f = 0; f < SF; ++f) {
+                        const int n = pr - f * hop;
+                        if (n >= 0 && n < N) { const float4 v = *(const float4*)(F + f * N + n); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+                    }
+                }
+                // window-sum-square over the frames that exist at these positions (librosa's window_sumsquare), by rotation
+                int t_hi = ip / hop; if (t_hi > a.n_frames - 1) t_hi = a.n_frames - 1;
+                int t_lo = (ip - N + hop) / hop; if (ip - N + 1 <= 0) t_lo = 0;
+                float c[4], sn[4], wss[4] = {0.f, 0.f, 0.f, 0.f};
+                sincospif(2.0f * (float)(ip - t_lo * hop) / (float)N, &sn[0], &c[0]);
+#pragma unroll
+                for (int j = 1; j < 4; ++j) { c[j] = c[j - 1] * cd - sn[j - 1] * sd; sn[j] = sn[j - 1] * cd + c[j - 1] * sd; }
+                for (int t = t_lo; t <= t_hi; ++t) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float w = 0.5f - 0.5f * c[j];
+                        wss[j] += w * w;
+                        const float cn = c[j] * ch + sn[j] * sh;                     // the next frame sees this sample hop taps earlier
+                        sn[j] = sn[j] * ch - c[j] * sh;
+                        c[j] = cn;
+                    }
+                }
+                float4 o;
+                o.x = wss[0] > 1.17549435e-38f ? acc.x / wss[0] : acc.x;
+                o.y = wss[1] > 1.17549435e-38f ? acc.y / wss[1] : acc.y;
+                o.z = wss[2] > 1.17549435e-38f ? acc.z / wss[2] : acc.z;
+                o.w = wss[3] > 1.17549435e-38f ? acc.w / wss[3] : acc.w;
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                *(float4*)(out + i0) = o;
+            }
+        }
+        __syncthreads();                                       // every reader of the old carry is done
+#pragma unroll
+        for (int it = 0; it < CARRY_IT; ++it) {
+            const int j = 4 * (threadIdx.x + it * BT);
+            if (j < NC) *(float4*)(carry + j) = nc[it];
+        }
+        __syncthreads();                                       // ... and F / x may be overwritten by the next group
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < BT / 64; ++i) mx = fmaxf(mx, red[i]);
+        partial[(long)sig * pl.nranges + rng] = mx;
+    }
+}
+
+// peak of signal blockIdx.y = max over its `nparts` partial peaks (max is exact in any order), then audio /= peak, 16 B per lane
+// where the row allows it (librosa.util.normalize(norm=inf): tiny peaks leave the clip as it is, utils.py:41-42)
+__global__ __launch_bounds__(256) void istft_peak_normalize_kernel(float* audio, int len, const float* partial, int nparts) {
+    __shared__ float red[4];
+    const int sig = blockIdx.y;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) mx = fmaxf(mx, partial[(long)sig * nparts + i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const float pk = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (!(pk > 1.17549435e-38f)) return;
+    float* row = audio + (long)sig * len;
+    if ((len & 3) == 0 && (((uintptr_t)audio) & 15) == 0) {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (len >> 2); i += gridDim.x * blockDim.x) {
+            float4 v = ((float4*)row)[i];
+            v.x /= pk; v.y /= pk; v.z /= pk; v.w /= pk;
+            ((float4*)row)[i] = v;
+        }
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) row[i] /= pk;
+    }
+}
+
 __global__ void frame_index_kernel(int n_samples, int n_fft, int hop, int n_frames, int* idx) {
     const long total = (long)n_frames * n_fft;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -458,9 +667,9 @@ __global__ __launch_bounds__(FFT_THREADS) void istft_frames_kernel(const pg_istf
         const float va = pa[(long)k * a.n_frames], vb = pb[(long)k * a.n_frames];
         float re, im;
         if (a.mode == 0) {                                           // demo.py:39: (exp(m) - 1) e^{j phi}
-            const float mag = expf(va) - 1.0f;
+            const float mag = pg_expm1_ref(va);
             float s, c;
-            sincosf(vb, &s, &c);
+            pg_sincos(vb, s, c);
             re = mag * c; im = mag * s;
         } else { re = va; im = vb; }
         const int bin = k + 1;
@@ -545,27 +754,6 @@ __global__ __launch_bounds__(256) void istft_ola4_kernel(const pg_istft_args a, 
     if (threadIdx.x == 0) partial[(long)sig * gridDim.x + blockIdx.x] = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
 }
 
-// per-signal peak = max over the workgroup partials (fixed order; max is exact in any order anyway)
-__global__ __launch_bounds__(256) void istft_peak_kernel(const float* partial, int nblk, unsigned* peak) {
-    __shared__ float scratch[4];
-    const int sig = blockIdx.x;
-    float mx = 0.f;
-    for (int i = threadIdx.x; i < nblk; i += 256) mx = fmaxf(mx, partial[(long)sig * nblk + i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) peak[sig] = __float_as_uint(fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3])));
-}
-
-__global__ __launch_bounds__(256) void istft_normalize_kernel(float* audio, int len, const unsigned* peak) {
-    const int sig = blockIdx.y;
-    const float pk = __uint_as_float(peak[sig]);
-    if (!(pk > 1.17549435e-38f)) return;                              // librosa.util.normalize: tiny norms -> leave as is
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x)
-        audio[(long)sig * len + i] /= pk;
-}
-
 // Griffin-Lim projection onto the target magnitudes: keep the phase of S, impose mag (utils.py:122-124)
 // (blockIdx.y = clip: S / spec_out (n, 2, bins, frames), mag (n, bins, frames), x (n, 2 bins - 2, frames))
 __global__ __launch_bounds__(256) void gl_project_kernel(const pg_gl_args a) {
@@ -634,6 +822,7 @@ hipError_t batched_lds_ready() {
     hipError_t e = hipFuncSetAttribute((const void*)stft_frames_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_frames_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_frames4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 4 * CARRY_IT * BT * 4);
     return e;
 }
 
@@ -675,9 +864,15 @@ static int64_t ola_partial_bytes(const pg_istft_args* a) {
     return (b + 255) / 256 * 256;
 }
 
+static int64_t fused_partial_bytes(const pg_istft_args* a, const IstftPlan& pl) {
+    return ((int64_t)a->n_signals * pl.nranges * (int64_t)sizeof(float) + 255) / 256 * 256;
+}
+
 extern "C" int64_t pg_workspace_bytes_istft(const pg_istft_args* a) {
     if (!a) return 0;
-    // [peak words, 256 B][per-workgroup peaks of the overlap-add, padded to 256 B][frames]
+    const IstftPlan pl = istft_plan(a->n_signals, a->bins, a->n_frames, a->hop, a->single_frame, pg_cu_count());
+    // fused path: [256 B reserved][per-workgroup peaks]; three-kernel path: [256 B][per-workgroup peaks of the overlap-add][frames]
+    if (pl.fused) return 256 + fused_partial_bytes(a, pl);
     return 256 + ola_partial_bytes(a) + (int64_t)a->n_signals * a->n_frames * 2 * a->bins * (int64_t)sizeof(float);
 }
 
@@ -688,11 +883,21 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
     if (a->n_signals <= 0 || a->n_signals > 64 || a->n_frames < 2 || a->hop <= 0 || a->hop > N) return pg_fail(PG_ERR_SHAPE, "istft: bad sizes (1..64 signals per call)");
     if (a->workspace_bytes < pg_workspace_bytes_istft(a)) return pg_fail(PG_ERR_WORKSPACE, "istft: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    unsigned* peak = (unsigned*)a->workspace;
     float* partial = (float*)((char*)a->workspace + 256);
-    float* frames = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));
     hipError_t e;
     if ((e = batched_lds_ready()) != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
+    const int len = a->hop * (a->n_frames - 1);
+    int bx = (len / 4 + 255) / 256; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
+    const IstftPlan pl = istft_plan(a->n_signals, a->bins, a->n_frames, a->hop, a->single_frame, pg_cu_count());
+    if (pl.fused) {
+        const int total = a->n_signals * pl.nranges, grid = 8 * ((total + 7) / 8);
+        const size_t lds = batched_lds(N) + (size_t)(N - a->hop) * sizeof(float);
+        hipLaunchKernelGGL(istft_fused_kernel, dim3((unsigned)grid), dim3(BT), lds, st, *a, partial, pl);
+        if (a->normalize) hipLaunchKernelGGL(istft_peak_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const float*)partial, pl.nranges);
+        e = hipGetLastError();
+        return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
+    }
+    float* frames = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));
     if (N <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
         hipLaunchKernelGGL(istft_frames4_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(N), st, *a, frames);
@@ -700,12 +905,9 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
         const size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
         hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)(a->n_signals * a->n_frames)), dim3(FFT_THREADS), lds, st, *a, frames);
     }
-    const int len = a->hop * (a->n_frames - 1);
     const int nblk = ola_blocks(a);
     hipLaunchKernelGGL(istft_ola4_kernel, dim3(nblk, a->n_signals), dim3(256), 0, st, *a, (const float*)frames, partial);
-    int bx = (len + 255) / 256; if (bx > 1024) bx = 1024;
-    if (a->normalize) hipLaunchKernelGGL(istft_peak_kernel, dim3(a->n_signals), dim3(256), 0, st, (const float*)partial, nblk, peak);
-    if (a->normalize) hipLaunchKernelGGL(istft_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const unsigned*)peak);
+    if (a->normalize) hipLaunchKernelGGL(istft_peak_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const float*)partial, nblk);
     e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
 }
@@ -733,7 +935,7 @@ extern "C" int pg_ola_nt(const pg_ola_args* a, void* stream) {
     const int len = a->hop * (a->frames - 1);
     int bx = (len + 255) / 256; if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(ola_nt_kernel, dim3(bx, n), dim3(256), 0, st, *a, peak);
-    if (a->normalize) hipLaunchKernelGGL(istft_normalize_kernel, dim3(bx, n), dim3(256), 0, st, a->audio, len, (const unsigned*)peak);
+    if (a->normalize) hipLaunchKernelGGL(istft_peak_normalize_kernel, dim3(bx > 256 ? 256 : bx, n), dim3(256), 0, st, a->audio, len, (const float*)peak, 1);
     e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
 }

@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphasegen.so")
+ABI_VERSION = 400     # include/phasegen.h PG_VERSION these struct layouts were written against (argument structs grow between minor versions)
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2           # pg_conv_args.precision
@@ -50,7 +51,8 @@ class BnArgs(C.Structure):
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
                 ("y_act", C.c_int32), ("y2_act", C.c_int32), ("y2", C.c_void_p), ("y2_bs", C.c_int64),
                 ("yh", C.c_void_p), ("yh_bs", C.c_int64), ("yh_pitch", C.c_int32), ("yh_act", C.c_int32),
-                ("yh2", C.c_void_p), ("yh2_bs", C.c_int64), ("yh2_pitch", C.c_int32), ("yh2_act", C.c_int32)]
+                ("yh2", C.c_void_p), ("yh2_bs", C.c_int64), ("yh2_pitch", C.c_int32), ("yh2_act", C.c_int32),
+                ("num_batches_tracked", C.c_void_p)]
 
 
 class ConvhArgs(C.Structure):
@@ -169,6 +171,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.pg_version() // 100 != ABI_VERSION // 100:
+        raise RuntimeError(f"{LIB_PATH} is ABI {lib.pg_version()}, this binding was written against {ABI_VERSION}: rebuild the library "
+                           "(`make -C unet-phasegen_amd/csrc`)")
     _lib = lib
     return lib
 

@@ -34,6 +34,7 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
         self.plans = {}
+        self.bytes = {}          # label -> algorithmic HBM bytes of ONE launch (the HBM-bound kernels: BatchNorm, loss, Adam)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -62,13 +63,19 @@ def _note_plan(a, op):
 
 
 class timed:
-    def __init__(self, label):
+    """``with ops.timed(label[, nbytes])``: one HIP-event pair around the launches inside, on the stream they go to (only while a
+    KernelTimer is installed; otherwise free).  ``nbytes``: algorithmic HBM bytes of the launch, for the HBM-side rooflines."""
+
+    def __init__(self, label, nbytes=None):
         self.label = label
+        self.nbytes = nbytes
 
     def __enter__(self):
         global _cur_label
         if _timer is not None:
             _cur_label = self.label
+            if self.nbytes is not None:
+                _timer.bytes[self.label] = self.nbytes
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record()
 
@@ -422,6 +429,13 @@ def conv_fwd_h(xh, Lin, wh, w_shape, stride, pad, transposed=False, y=None, yh=N
     if xh.shape[1] != Cin:
         raise ValueError(f"conv_fwd_h: x has {xh.shape[1]} channels, weight expects {Cin}")
     a.x, a.x_bs, a.x_pitch = _h3(xh, Lin + 1, "xh")
+    # v0.3 layout contract: the kernels gather the window of row (0, 0) from up to PG_H_HEAD elements IN FRONT of the tensor (the
+    # convolution's left padding is read, not synthesised).  The C side only sees a pointer; here the storage is visible: a tensor
+    # that starts closer than H_HEAD elements to the beginning of its allocation (plain torch.zeros(B, C, pitch) instead of
+    # ops.h_alloc) would make the kernel read in front of the allocation -- foreign bytes as padding, or a GPU memory fault.
+    if xh.storage_offset() < H_HEAD:
+        raise ValueError(f"conv_fwd_h: xh starts {xh.storage_offset()} elements into its allocation; the bf16-resident kernels read "
+                         f"{H_HEAD} zero elements in front of it -- allocate activations with ops.h_alloc (or pass a channel slice)")
     if wh.dtype != torch.bfloat16 or wh.numel() != _lib.load().pg_shadow_elems(Cin, Cout, k, stride, int(transposed)):
         raise ValueError("conv_fwd_h: wh must be the bf16 shadow of the layer's weight (ops.shadow_weights)")
     _on_current_device(wh, "wh")
@@ -452,7 +466,9 @@ def conv_fwd_h_describe(a):
 
 
 def bn_fwd(x, y, gamma, beta, save_mean, save_invstd, running_mean=None, running_var=None, eps=1e-5, momentum=0.1,
-           y_act=ACT_NONE, y2=None, y2_act=ACT_NONE, yh=None, yh_act=ACT_NONE, yh2=None, yh2_act=ACT_NONE):
+           y_act=ACT_NONE, y2=None, y2_act=ACT_NONE, yh=None, yh_act=ACT_NONE, yh2=None, yh2_act=ACT_NONE, num_batches_tracked=None):
+    """Train-mode BatchNorm forward (model.py:81,83).  ``num_batches_tracked``: the layer's int64 counter (0-d device tensor),
+    incremented by the kernel itself -- no extra launch."""
     a = _lib.BnArgs()
     a.y_act, a.y2_act = y_act, y2_act
     if y2 is not None:
@@ -472,6 +488,8 @@ def bn_fwd(x, y, gamma, beta, save_mean, save_invstd, running_mean=None, running
     a.save_mean, a.save_invstd = _dense(save_mean, "save_mean"), _dense(save_invstd, "save_invstd")
     if running_mean is not None:
         a.running_mean, a.running_var = _dense(running_mean, "running_mean"), _dense(running_var, "running_var")
+    if num_batches_tracked is not None:
+        a.num_batches_tracked = _dense_as(num_batches_tracked, torch.int64, "num_batches_tracked")
     _lib.check(_lib.load().pg_bn_fwd(C.byref(a), _stream()), "bn_fwd")
     return y
 

@@ -176,7 +176,8 @@ class Trainer:
         dpred = self._dpred.get(pred.shape)
         if dpred is None:
             dpred = self._dpred[pred.shape] = torch.empty_like(pred)
-        self._loss(pred, batch, dpred, self.losses, self.mag_weight)
+        with ops.timed("hbm:loss", 12 * pred.numel()):           # per bin-frame: logmag, angle, two predictions read, two gradients written (24 B)
+            self._loss(pred, batch, dpred, self.losses, self.mag_weight)
         if not self.overlap_adam:
             self.engine.backward(dpred, self.reducer.launch)
             self.reducer.wait_all()
@@ -218,7 +219,8 @@ class Trainer:
             for name in self._due:
                 s, e = self.reducer.buckets.spans[name]
                 self.reducer.wait(name)                      # data parallel: the bucket's all-reduce (RCCL's stream) is awaited HERE,
-                self.optim.step_range(s, e, 1.0 / self.world)   # on the side stream, not on the stream that runs backward
+                with ops.timed("hbm:adam." + name, 28 * (e - s)):   # on the side stream, not on the stream that runs backward
+                    self.optim.step_range(s, e, 1.0 / self.world)
         self._due.clear()
 
     # -- checkpoint / resume.  The reference saves the model only (model.py:45-48) and cannot

@@ -191,9 +191,10 @@ class UNetEngine:
         sm, si = self.bn_save[name]
         rm = a.buffers[key + ".running_mean"] if update_stats else None
         rv = a.buffers[key + ".running_var"] if update_stats else None
-        ops.bn_fwd(x, y, a.p(key + ".weight"), a.p(key + ".bias"), sm, si, rm, rv, y_act=y_act, y2=y2, y2_act=y2_act)
-        if update_stats:
-            a.buffers[key + ".num_batches_tracked"] += 1
+        nb = a.buffers[key + ".num_batches_tracked"] if update_stats else None
+        with ops.timed("hbm:bn_fwd." + name, 4 * x.numel() * (2 + (y2 is not None))):        # one read, one or two fp32 writes
+            ops.bn_fwd(x, y, a.p(key + ".weight"), a.p(key + ".bias"), sm, si, rm, rv, y_act=y_act, y2=y2, y2_act=y2_act,
+                       num_batches_tracked=nb)
 
     # -- bf16-resident inference forward (BASELINE configs[4]) ----------------------------------------------------------------
     RESIDENT_LAYERS = ("D0", "D1", "D2", "D3", "U3", "U2", "U1", "U0")  # U3 (k = 5): shadow padded to 4 taps per phase
@@ -262,18 +263,25 @@ class UNetEngine:
         if not self.graphs or ops._timer is not None:
             self._resident_body(plan, sh, update_stats)
         else:
-            key = ("graph", B, L, bool(update_stats))
+            # everything a capture freezes is part of the key: shape, the BatchNorm-buffer update, the thread's schedule word and the
+            # engine's precision (ops reads both at launch time; a replay would silently keep the captured ones)
+            key = ("graph", B, L, bool(update_stats), ops.current_schedule(), self.precision)
             g = self.plans.get(key)
-            if g is None:                        # first forward at this shape: eager (creates the workspaces the graph will reference)
+            if g is None:                        # first forward at this shape: eager (first-launch costs stay out of the capture)
                 self._resident_body(plan, sh, update_stats)
                 self.plans[key] = "warm"
             else:
                 if g == "warm":                  # second: capture -- nothing executes while capturing -- then replay as this call's forward
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
                         self._resident_body(plan, sh, update_stats)
-                    self.plans[key] = g
-                g.replay()
+                        # ops' scratch caches are keyed by (device, CURRENT stream) and torch captures on a side stream of its own:
+                        # the stream-K workspace the captured launches point at was allocated just now, for the capture stream.  It
+                        # is held HERE, next to the graph, so that neither the caches' LRU eviction nor ops.release_workspaces()
+                        # can free memory a live graph still references.
+                        held = ops.conv_workspace(self.device)
+                    g = self.plans[key] = (graph, held)
+                g[0].replay()
         self.fwd_count += 1
         self.cur = None                      # nothing kept for backward
         return f["out"]
@@ -295,9 +303,8 @@ class UNetEngine:
             sm, si = self.bn_save[name]
             rm = a.buffers[key + ".running_mean"] if update_stats else None
             rv = a.buffers[key + ".running_var"] if update_stats else None
-            ops.bn_fwd(raw, out.pop("y", None), a.p(key + ".weight"), a.p(key + ".bias"), sm, si, rm, rv, **out)
-            if update_stats:
-                a.buffers[key + ".num_batches_tracked"] += 1
+            nb = a.buffers[key + ".num_batches_tracked"] if update_stats else None
+            ops.bn_fwd(raw, out.pop("y", None), a.p(key + ".weight"), a.p(key + ".bias"), sm, si, rm, rv, num_batches_tracked=nb, **out)
 
         conv("D0", f["x0"], L, yh=f["l0"], yh_act=ACT_LEAKY, yh2=f["cat0"][:, :h], yh2_act=ACT_RELU)
         conv("D1", f["l0"], L1, y=f["c1"])
@@ -382,7 +389,8 @@ class UNetEngine:
         def bn_bwd(name, raw, dy, dx):
             key = BN_OF[name]
             sm, si = self.bn_save[name]
-            ops.bn_bwd(raw, dy, dx, a.p(key + ".weight"), sm, si, a.g(key + ".weight"), a.g(key + ".bias"))
+            with ops.timed("hbm:bn_bwd." + name, 12 * raw.numel()):                         # x and dy read, dx written
+                ops.bn_bwd(raw, dy, dx, a.p(key + ".weight"), sm, si, a.g(key + ".weight"), a.g(key + ".bias"))
 
         def wgrad(name, x, dy, act):
             key, kind, s, p = LAYERS[name]

@@ -20,14 +20,20 @@ def validation_metrics(model, val_batch, hop_length=512, n_fft=2048, gl_iters=25
     ``shard=True`` (data-parallel training; EVERY rank of ``group`` must call it with the same batch): rank r evaluates clips
     r::W and the sums are all-reduced, so no rank sits in the next gradient all-reduce while another one validates, and the
     250 Griffin-Lim iterations run on W GPUs.  Clip c draws its Griffin-Lim start with seed gl_seed + c on whichever rank it
-    lands: the result does not depend on W (up to the order of the final fp32 sums)."""
+    lands: the result does not depend on W (up to the order of the final fp32 sums).
+    BatchNorm buffers: the forwards are train-mode and update running_mean / running_var / num_batches_tracked (the reference's
+    validation does, train.py:76 runs the model as it is), so sharded ranks see different clips and their buffers would drift apart;
+    after the sharded forwards rank 0's buffers are broadcast, which keeps the replicas identical (what Trainer's construction-time
+    check asserts once).  The values then depend on W -- rank 0 saw clips 0, W, 2W, ... -- and on nothing else; the model never reads
+    them (no .eval() anywhere), they only travel in checkpoints.
+    A non-finite Griffin-Lim or ISTFT result raises, as librosa.util.valid_audio does in the reference (utils.py:41,130)."""
     import torch.distributed as dist
     val_batch = val_batch.contiguous()
     n, _, bins, _ = val_batch.shape
     world = dist.get_world_size(group) if (shard and dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
     mine = list(range(rank, n, world))
-    sums = torch.zeros(4, device=val_batch.device, dtype=torch.float64)           # sum |orig - hyb|, |orig - nop|, |orig - lim|, elements
+    sums = torch.zeros(5, device=val_batch.device, dtype=torch.float64)   # sum |orig - hyb|, |orig - nop|, |orig - lim|, elements, non-finite
     if mine:
         vb = val_batch[mine]
         logmag, ang = vb[:, 0].contiguous(), vb[:, 1].contiguous()
@@ -42,8 +48,16 @@ def validation_metrics(model, val_batch, hop_length=512, n_fft=2048, gl_iters=25
         sums[1] = torch.abs(orig - nop).double().sum()
         sums[2] = torch.abs(orig - lim).double().sum()
         sums[3] = orig.numel()
+        sums[4] = sum((~torch.isfinite(t)).sum() for t in (orig, hyb, nop, lim)).double()
     if world > 1:
         dist.all_reduce(sums, group=group)
+        arena = model.engine.arena
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        for k in sorted(arena.buffers):
+            dist.broadcast(arena.buffers[k], src=src, group=group)
     # (clips have equal length: the mean over everything == the reference's mean of per-clip means, train.py:122)
-    res = (sums[:3] / sums[3]).cpu()
+    host = sums.cpu()
+    if host[4] != 0:
+        raise ValueError("Audio buffer is not finite everywhere")      # librosa.util.valid_audio's message (utils.py:41,130)
+    res = host[:3] / host[3]
     return {"MSE": float(res[0]), "NOPMSE": float(res[1]), "LMSE": float(res[2])}
