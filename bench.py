@@ -558,8 +558,9 @@ def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf1
                 "bound": "hbm", "peak_TBps": PEAK_HBM_TBPS, "traffic": tr, "traffic_ratio": round(tr / nbytes, 2) if tr else None,
                 "traffic_source": t[0][1], "kernels": kernels}
     nf = nsig * frames
-    stage_roofline = {"stft+polar": stage(stage[0] / 3, nf * (hop * 4 + n_fft * 4), ["stft_frames_kernel<false>"]),
-                      "istft": stage(stage[2] / 3, nf * (n_fft * 4 + hop * 4 + 2 * hop * 4), ["istft_fused_kernel", "istft_peak_normalize_kernel"])}
+    stage_roofline = {"stft+polar": stage(stage[0] / 3, nf * (hop * 4 + n_fft * 4), ["stft_w_kernel<false>"]),
+                      "istft": stage(stage[2] / 3, nf * (n_fft * 4 + hop * 4 + 2 * hop * 4),
+                                     ["istft_frames_w_kernel", "istft_ola4_kernel", "istft_peak_normalize_kernel"])}
     return {
         "metric": "spectrogram-frames/sec end to end (STFT + U-Net forward + ISTFT)", "value": world * nsig * frames / sec,
         "unit": "frames/s", "clips_per_s": world * clips / sec, "n_gpus": world, "steps": steps, "warmup": warmup,

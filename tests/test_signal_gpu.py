@@ -123,15 +123,16 @@ def test_polar_arithmetic_against_float64():
     assert np.max(rel) < 6e-7, float(np.max(rel))
     k = len(special)
     sp = out[1][2 * n:2 * n + k]
-    assert sp[0] == 0.0 and sp[1] == np.float32(np.pi) and sp[4] == 0.0 and sp[5] == np.float32(np.pi)   # origin, -0 real axis, axes exact
+    # origin (also with a -0.0 real part: data.py:40's complex arithmetic turns it into +0.0) and the axes are exact; (-1, -0.0) is the
+    # reference's quirk: the imaginary -0.0 becomes +0.0, so the angle is +pi, not -pi
+    assert sp[0] == 0.0 and sp[1] == 0.0 and sp[4] == 0.0 and sp[5] == np.float32(np.pi) and sp[8] == np.float32(np.pi)
     assert sp[6] == np.float32(np.pi / 2) and sp[7] == np.float32(-np.pi / 2)
 
 
-@pytest.mark.parametrize("bins,frames,hop,nsig", [(1024, 256, 512, 3), (512, 64, 256, 2), (64, 37, 32, 2)])
-def test_istft_synthesis_arithmetic_and_fused_path(bins, frames, hop, nsig):
+@pytest.mark.parametrize("bins,frames,hop,nsig", [(1024, 256, 512, 3), (512, 64, 256, 2), (64, 36, 32, 2), (32, 44, 16, 1)])
+def test_istft_synthesis_arithmetic(bins, frames, hop, nsig):
     """(1) mode 0 = (exp(m) - 1) e^{j phi} on v_exp_f32 and the polynomial sincos (pg_fastmath.h) equals mode 1 fed the same
-    spectrum formed in float64; (2) the fused kernel (frames + overlap-add + peaks in one launch, ranges with halo groups and flush
-    groups) equals the one-frame-per-workgroup schedule, which still runs the three-kernel path."""
+    spectrum formed in float64; (2) the two transform schedules agree; (3) peak normalisation really ends at a peak of 1."""
     from phasegen import ops
     m = np.abs(detgen.normal(41, (nsig, bins, frames))).astype(np.float32) * 2.0
     phi = (detgen.normal(42, (nsig, bins, frames)) * 4.0).astype(np.float32)          # beyond (-pi, pi]: the network's output is unbounded

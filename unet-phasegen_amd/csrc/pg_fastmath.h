@@ -2,7 +2,7 @@
 // (exp(m) - 1) e^{j phi}), written for the VALU budget of an HBM-bound kernel.  libm's hypotf + log1pf + atan2f cost ~115 VALU
 // instructions per bin-frame (63 us of the 164 us fused STFT at 64 x 256 frames of 2048 points, measured round 3); sincosf with its
 // Payne-Hanek tail ~100.  These take ~40 and ~22.  Accuracy (float64 reference, tests/test_signal_gpu.py and the G4 golden of the
-// imported data.py at 2e-6 absolute): atan2 <= 3e-7 rad, log1p <= 2.5e-7 relative, sincos <= 2.5e-7 absolute for |phi| <= 100.
+// imported data.py at 2e-6 absolute): atan2 <= 3e-7 rad, log1p <= 1 ulp, sincos <= 2.5e-7 absolute for |phi| <= 100.
 // Branch cuts are atan2f's own (signed zeros, both axes exact).  Coefficients: tools/fit/fit_math.py (Remez on the absolute error,
 // checked in float32 Horner arithmetic).  One definition each, used by every kernel that needs it, so that the fused STFT+polar
 // kernel and the standalone polar kernel stay bit-identical.
@@ -40,11 +40,12 @@ __device__ __forceinline__ float pg_atan2(float y, float x) {
     return copysignf(r, y);
 }
 
-// log1p(x) for x >= 0: log(u) * x / (u - 1) with u = fl(1 + x) -- the rounding of 1 + x is divided out again.
+// log1p(x) for x >= 0: log(u) + ((1 + x) - u) / u with u = fl(1 + x).  The rounding error of the addition, (1 + x) - u = x - (u - 1),
+// is exact in float32 and enters to first order only, so the result is as good as logf(u): <= 1 ulp (the G4 golden of the imported
+// data.py holds at 1e-7 absolute).  x tiny: logf(1) + x = x.
 __device__ __forceinline__ float pg_log1p_pos(float x) {
     const float u = 1.0f + x, d = u - 1.0f;
-    const float l = __builtin_amdgcn_logf(u) * 0.693147180559945309f;       // v_log_f32 is log2
-    return d == 0.0f ? x : l * (x * __builtin_amdgcn_rcpf(d));
+    return logf(u) + (x - d) * __builtin_amdgcn_rcpf(u);
 }
 
 // |re + j im| without hypotf's scaling ladder: exact power-of-two pre-scaling only where the squares would leave the normal range

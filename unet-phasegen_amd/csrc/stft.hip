@@ -18,9 +18,15 @@
 #define PG_STFT_ABL 0
 #endif
 
+
 namespace {
 
 constexpr int FFT_THREADS = 256;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL load and store
+// (s_waitcnt vmcnt(0)), which serialises a prefetch issued in front of the FFT passes with the passes it was meant to hide under;
+// this one leaves vector-memory operations in flight (the compiler still waits for a load's registers at their first use).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // numpy 'reflect' padding (edge sample not repeated): index into y[0..n) of position pos (may be <0 or >=n)
 __device__ __host__ __forceinline__ int reflect_index(int pos, int n) {
@@ -149,8 +155,8 @@ __device__ void fill_tw4(float2* tw, int M, float sign) {
 
 // M-point complex transforms of SF frames stored as x[f*M + swz(e)]; DIR = +1 forward, -1 inverse (unnormalised).
 // Returns the buffer holding the natural-order result.  Ends with a barrier.
-template <int DIR>
-__device__ float2* fft_frames(float2* x, float2* y, const float2* tw, int M) {
+template <int DIR, int PF, int UNR = PF>   // PF frames per thread: a workgroup of 256 FG threads transforms FG x PF frames; UNR of them
+__device__ float2* fft_frames_t(float2* x, float2* y, const float2* tw, int M) {      // in flight at once (register budget of the caller)
     const int q = M >> 2, TL = tw_len(M);
     const int jt = threadIdx.x & 255, f0 = (int)(threadIdx.x >> 8) * PF;
     x += f0 * M; y += f0 * M;                      // this thread's frames (the swap below keeps the offset)
@@ -163,7 +169,7 @@ __device__ float2* fft_frames(float2* x, float2* y, const float2* tw, int M) {
             const int i0 = swz(j), i1 = swz(j + q), i2 = swz(j + 2 * q), i3 = swz(j + 3 * q);
             const int j0 = ((j - k) << 2) + k;
             const int o0 = swz(j0), o1 = swz(j0 + Ns), o2 = swz(j0 + 2 * Ns), o3 = swz(j0 + 3 * Ns);
-#pragma unroll
+#pragma unroll(UNR)
             for (int f = 0; f < PF; ++f) {
                 const float2* xf = x + f * M;
                 float2* yf = y + f * M;
@@ -178,7 +184,7 @@ __device__ float2* fft_frames(float2* x, float2* y, const float2* tw, int M) {
                 yf[o3] = make_float2(s1.x - r3.x, s1.y - r3.y);
             }
         }
-        __syncthreads();
+        lds_barrier();
         float2* t = x; x = y; y = t;
     }
     if (Ns < M) {                                  // log2 M odd: one closing radix-2 pass, twiddle computed in place
@@ -188,18 +194,19 @@ __device__ float2* fft_frames(float2* x, float2* y, const float2* tw, int M) {
             sincospif((DIR > 0 ? -1.0f : 1.0f) * (float)j / (float)half, &sn, &cs);       // k = j here: Ns == half
             const float2 w = make_float2(cs, sn);
             const int i0 = swz(j), i1 = swz(j + half), o0 = swz(j), o1 = swz(j + half);
-#pragma unroll
+#pragma unroll(UNR)
             for (int f = 0; f < PF; ++f) {
                 const float2 a = x[f * M + i0], v = cmul(x[f * M + i1], w);
                 y[f * M + o0] = make_float2(a.x + v.x, a.y + v.y);
                 y[f * M + o1] = make_float2(a.x - v.x, a.y - v.y);
             }
         }
-        __syncthreads();
+        lds_barrier();
         float2* t = x; x = y; y = t;
     }
     return x - f0 * M;
 }
+template <int DIR> __device__ __forceinline__ float2* fft_frames(float2* x, float2* y, const float2* tw, int M) { return fft_frames_t<DIR, PF>(x, y, tw, M); }
 
 // one output row, SF consecutive frames: a 16 B store when the row segment is aligned, scalar stores otherwise
 __device__ __forceinline__ void stft_store_row(const pg_stft_args& a, float* o_re, float* o_im, long row, int nfr, bool vec,
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(BT) void stft_frames_kernel(const pg_stft_args a) {
                 for (int f = 0; f < SF; ++f) x[f * M + e] = make_float2(pre[i][f].x * w0[i], pre[i][f].y * w1[i]);
             }
         }
-        __syncthreads();
+        lds_barrier();
 #if PG_STFT_ABL != 3
         if (gw.g + gw.step < gw.end) load_group(gw.g + gw.step);
 #endif
@@ -338,33 +345,41 @@ __global__ __launch_bounds__(BT) void stft_frames_kernel(const pg_stft_args a) {
             for (int f = 0; f < SF; ++f) { const float2 Z0 = Z[f * M]; rn[f] = Z0.x - Z0.y; in[f] = 0.f; }
             stft_store_row(a, o_re, o_im, M - 1, nfr, vec, rn, in);
         }
-        __syncthreads();                                                      // Z may live in the buffer the next group loads into
+        lds_barrier();                                                      // Z may live in the buffer the next group loads into
     }
 }
 
-// SF consecutive frames of spectrum row `bin` (1-based FFT bin) as complex values; frames past the end read as zero
-__device__ __forceinline__ void istft_row(const pg_istft_args& a, const float* pa, const float* pb, int bin, int nfr, bool vec,
-                                          float2 (&X)[SF]) {
-    float va[SF], vb[SF];
+// SF consecutive frames of spectrum row `bin` (1-based FFT bin): the raw values of both tensors (frames past the end read as zero) ...
+struct RowRaw { float va[SF], vb[SF]; };
+__device__ __forceinline__ void istft_row_load(const pg_istft_args& a, const float* pa, const float* pb, int bin, int nfr, bool vec, RowRaw& r) {
     const float* ra = pa + (long)(bin - 1) * a.n_frames;
     const float* rb = pb + (long)(bin - 1) * a.n_frames;
     if (vec) {
         const float4 qa = *(const float4*)ra, qb = *(const float4*)rb;
-        va[0] = qa.x; va[1] = qa.y; va[2] = qa.z; va[3] = qa.w;
-        vb[0] = qb.x; vb[1] = qb.y; vb[2] = qb.z; vb[3] = qb.w;
+        r.va[0] = qa.x; r.va[1] = qa.y; r.va[2] = qa.z; r.va[3] = qa.w;
+        r.vb[0] = qb.x; r.vb[1] = qb.y; r.vb[2] = qb.z; r.vb[3] = qb.w;
     } else {
 #pragma unroll
-        for (int f = 0; f < SF; ++f) { va[f] = f < nfr ? ra[f] : 0.f; vb[f] = f < nfr ? rb[f] : 0.f; }
+        for (int f = 0; f < SF; ++f) { r.va[f] = f < nfr ? ra[f] : 0.f; r.vb[f] = f < nfr ? rb[f] : 0.f; }
     }
+}
+// ... and their complex values
+__device__ __forceinline__ void istft_row_cvt(int mode, const RowRaw& r, float2 (&X)[SF]) {
 #pragma unroll
     for (int f = 0; f < SF; ++f) {
-        if (a.mode == 0) {                                                // demo.py:39: (exp(m) - 1) e^{j phi}
-            const float mag = pg_expm1_ref(va[f]);
+        if (mode == 0) {                                                  // demo.py:39: (exp(m) - 1) e^{j phi}
+            const float mag = pg_expm1_ref(r.va[f]);
             float s, c;
-            pg_sincos(vb[f], s, c);
+            pg_sincos(r.vb[f], s, c);
             X[f] = make_float2(mag * c, mag * s);
-        } else X[f] = make_float2(va[f], vb[f]);
+        } else X[f] = make_float2(r.va[f], r.vb[f]);
     }
+}
+__device__ __forceinline__ void istft_row(const pg_istft_args& a, const float* pa, const float* pb, int bin, int nfr, bool vec,
+                                          float2 (&X)[SF]) {
+    RowRaw r;
+    istft_row_load(a, pa, pb, bin, nfr, vec, r);
+    istft_row_cvt(a.mode, r, X);
 }
 
 __global__ __launch_bounds__(BT) void istft_frames4_kernel(const pg_istft_args a, float* frames) {
@@ -417,7 +432,7 @@ __global__ __launch_bounds__(BT) void istft_frames4_kernel(const pg_istft_args a
 #pragma unroll
             for (int f = 0; f < SF; ++f) x[f * M] = make_float2(0.5f * Xn[f].x, -0.5f * Xn[f].x);
         }
-        __syncthreads();
+        lds_barrier();
         const float2* z = fft_frames<-1>(x, y, tw, M);
 #pragma unroll
         for (int i = 0; i < M_ITERS; ++i) {
@@ -433,191 +448,7 @@ __global__ __launch_bounds__(BT) void istft_frames4_kernel(const pg_istft_args a
                 }
             }
         }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Fused ISTFT (round 4): inverse frames, windowing, overlap-add, window-sum-square division, n_fft/2 trim and the per-workgroup
-// peak in ONE kernel -- the frame workspace (written, re-read: 2 x 134 MB at 64 x 256 frames of 2048 points) is gone.
-// A workgroup owns a RANGE of consecutive frame groups of one signal and walks them in order.  Per group (SF frames): spectrum rows
-// -> Hermitian half-length input -> radix-4 passes (as istft_frames4_kernel) -> the windowed real frames go to the ping-pong buffer
-// the transform does not end in (F, SF x n_fft floats) -> every output position the group completes, [t0 hop, (t0 + SF) hop), is the
-// sum of a CARRY (partial sums left by earlier frames, n_fft - hop floats of LDS) and the group's frames, read as 16 B pieces ->
-// divided by the analytic window-sum-square and stored once, 16 B per lane, coalesced; the group's tails become the next carry.
-// A range that does not start at frame 0 first runs the group in front of it for its carry only (the halo: n_fft <= (SF + 1) hop
-// guarantees one group suffices), and groups past the last frame flush the carry.  Needs hop % 4 == 0 and n_fft <= (SF + 1) hop;
-// other shapes keep the three-kernel path below.
-constexpr int CARRY_IT = 2;              // (n_fft - hop) / 4 float4 <= 2 x BT for n_fft <= 2048
-
-struct IstftPlan { int fused, rg, nranges, gs; };
-__host__ __device__ inline IstftPlan istft_plan(int n_signals, int bins, int n_frames, int hop, int single_frame, int cus) {
-    IstftPlan pl = {0, 0, 0, 0};
-    const int N = 2 * bins;
-    if (single_frame || N > 2 * MAX_HALF || (hop & 3) || N > (SF + 1) * hop || hop > N || (N - hop) > 4 * CARRY_IT * BT || n_frames < 2) return pl;
-    const long padded = (long)(N >> 1) + (long)hop * (n_frames - 1);              // positions [0, padded) hold every trimmed output
-    pl.gs = (int)((padded + (long)SF * hop - 1) / ((long)SF * hop));               // groups that complete them (the last ones flush)
-    const int fg = (n_frames + SF - 1) / SF;                                      // groups that hold frames
-    int rg = (int)(((long)n_signals * fg) / (2L * cus));                          // aim at two workgroups per CU ...
-    rg = rg < 2 ? 2 : (rg > 8 ? 8 : rg);                                          // ... with 2..8 groups each (halo: one extra group)
-    pl.rg = rg;
-    pl.nranges = fg / rg < 1 ? 1 : fg / rg;                                       // the last range takes the remainder and the flush
-    pl.fused = 1;
-    return pl;
-}
-
-__global__ __launch_bounds__(BT) void istft_fused_kernel(const pg_istft_args a, float* partial, const IstftPlan pl) {
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    __shared__ float red[BT / 64];
-    const int M = a.bins, N = 2 * M, hop = a.hop;
-    float2* x = smem; float2* y = smem + SF * M; float2* tw = smem + 2 * SF * M;
-    float* carry = (float*)(tw + 3 * tw_len(M));
-    const int NC = N - hop;                                   // carry length
-    // workgroup -> (signal, range): consecutive ranges of a signal sit behind the same L2 (workgroups are dealt round-robin over XCDs)
-    const int total = a.n_signals * pl.nranges, chunk = (total + 7) >> 3, xcd = blockIdx.x & 7;
-    const int id = xcd * chunk + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || id >= total) return;
-    const int sig = id / pl.nranges, rng = id - sig * pl.nranges;
-    const int g_begin = rng * pl.rg, g_end = rng == pl.nranges - 1 ? pl.gs : (rng + 1) * pl.rg;
-    const int len = hop * (a.n_frames - 1);
-    fill_tw4(tw, M, 1.f);
-    float w0[M_ITERS], w1[M_ITERS], sc[K_ITERS], ss[K_ITERS];
-    const float inv = 1.0f / (float)M;
-#pragma unroll
-    for (int i = 0; i < M_ITERS; ++i) {
-        const int m = threadIdx.x + i * BT;
-        w0[i] = inv * hann(2 * m, N); w1[i] = inv * hann(2 * m + 1, N);
-    }
-#pragma unroll
-    for (int i = 0; i < K_ITERS; ++i)
-        sincospif((float)(1 + threadIdx.x + i * BT) / (float)M, &ss[i], &sc[i]);    // exp(+2 pi i k / n_fft)
-    for (int j = threadIdx.x; j < NC; j += BT) carry[j] = 0.f;
-    const bool vec4 = (a.n_frames & 3) == 0 && ((a.a_bs | a.b_bs) & 3) == 0 && ((((uintptr_t)a.a) | ((uintptr_t)a.b)) & 15) == 0;
-    float sd, cd, sh, ch;                                     // window rotations: one sample, one hop
-    sincospif(2.0f / (float)N, &sd, &cd);
-    sincospif(2.0f * (float)hop / (float)N, &sh, &ch);
-    float* out = a.audio + (long)sig * len;
-    float mx = 0.f;
-    __syncthreads();
-    for (int g = g_begin > 0 ? g_begin - 1 : 0; g < g_end; ++g) {
-        const bool halo = g < g_begin;
-        const int t0 = g * SF;
-        const int nfr = a.n_frames - t0 < 0 ? 0 : (a.n_frames - t0 > SF ? SF : a.n_frames - t0);
-        const float* F = nullptr;                             // SF windowed frames of n_fft floats; nullptr: no frame left (flush)
-        if (nfr > 0) {
-            const float* pa = a.a + (long)sig * a.a_bs + t0;
-            const float* pb = a.b + (long)sig * a.b_bs + t0;
-            const bool vec = vec4 && nfr == SF;
-#pragma unroll
-            for (int i = 0; i < K_ITERS; ++i) {               // Z[k] = E[k] + i O[k] (see istft_frames4_kernel)
-                const int k = 1 + threadIdx.x + i * BT;
-                if (k <= (M >> 1)) {
-                    const int ea = swz(k), eb = swz(M - k);
-                    float2 Xk[SF], Xm[SF];
-                    istft_row(a, pa, pb, k, nfr, vec, Xk);
-                    istft_row(a, pa, pb, M - k, nfr, vec, Xm);
-#pragma unroll
-                    for (int f = 0; f < SF; ++f) {
-                        const float2 E = make_float2(0.5f * (Xk[f].x + Xm[f].x), 0.5f * (Xk[f].y - Xm[f].y));
-                        const float2 D = make_float2(0.5f * (Xk[f].x - Xm[f].x), 0.5f * (Xk[f].y + Xm[f].y));
-                        const float2 O = cmul(D, make_float2(sc[i], ss[i]));
-                        x[f * M + ea] = make_float2(E.x - O.y, E.y + O.x);
-                        if (k != M - k) x[f * M + eb] = make_float2(E.x + O.y, O.x - E.y);
-                    }
-                }
-            }
-            if (threadIdx.x == 0) {
-                float2 Xn[SF];
-                istft_row(a, pa, pb, M, nfr, vec, Xn);
-#pragma unroll
-                for (int f = 0; f < SF; ++f) x[f * M] = make_float2(0.5f * Xn[f].x, -0.5f * Xn[f].x);
-            }
-            __syncthreads();
-            const float2* z = fft_frames<-1>(x, y, tw, M);
-            float2* Fw = (z == x) ? y : x;
-#pragma unroll
-            for (int i = 0; i < M_ITERS; ++i) {
-                const int m = threadIdx.x + i * BT;
-                if (m < M) {
-                    const int e = swz(m);
-#pragma unroll
-                    for (int f = 0; f < SF; ++f) {            // frames past the end were built from zero rows: they hold zeros
-                        const float2 v = z[f * M + e];
-                        Fw[f * M + m] = make_float2(v.x * w0[i], v.y * w1[i]);
-                    }
-                }
-            }
-            F = (const float*)Fw;
-            __syncthreads();
-        }
-        // the next carry: positions (t0 + SF) hop + j, j < n_fft - hop, as far as this group's frames reach them
-        float4 nc[CARRY_IT];
-#pragma unroll
-        for (int it = 0; it < CARRY_IT; ++it) {
-            nc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int j = 4 * (threadIdx.x + it * BT);
-            if (F && j < NC) {
-#pragma unroll
-                for (int f = 0; f < SF; ++f) {
-                    const int n = (SF - f) * hop + j;
-                    if (n < N) { const float4 v = *(const float4*)(F + f * N + n); nc[it].x += v.x; nc[it].y += v.y; nc[it].z += v.z; nc[it].w += v.w; }
-                }
-            }
-        }
-        if (!halo) {
-            for (int pr = 4 * threadIdx.x; pr < SF * hop; pr += 4 * BT) {          // positions t0 hop + pr .. + 3 (padded coordinates)
-                const int ip = t0 * hop + pr, i0 = ip - (N >> 1);
-                if (i0 < 0 || i0 >= len) continue;                                   // trimmed away (len, n_fft / 2, hop: multiples of 4)
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pr < NC) acc = *(const float4*)(carry + pr);
-                if (F) {
-#pragma unroll
-                    for (int f = 0; f < SF; ++f) {
-                        const int n = pr - f * hop;
-                        if (n >= 0 && n < N) { const float4 v = *(const float4*)(F + f * N + n); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-                    }
-                }
-                // window-sum-square over the frames that exist at these positions (librosa's window_sumsquare), by rotation
-                int t_hi = ip / hop; if (t_hi > a.n_frames - 1) t_hi = a.n_frames - 1;
-                int t_lo = (ip - N + hop) / hop; if (ip - N + 1 <= 0) t_lo = 0;
-                float c[4], sn[4], wss[4] = {0.f, 0.f, 0.f, 0.f};
-                sincospif(2.0f * (float)(ip - t_lo * hop) / (float)N, &sn[0], &c[0]);
-#pragma unroll
-                for (int j = 1; j < 4; ++j) { c[j] = c[j - 1] * cd - sn[j - 1] * sd; sn[j] = sn[j - 1] * cd + c[j - 1] * sd; }
-                for (int t = t_lo; t <= t_hi; ++t) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float w = 0.5f - 0.5f * c[j];
-                        wss[j] += w * w;
-                        const float cn = c[j] * ch + sn[j] * sh;                     // the next frame sees this sample hop taps earlier
-                        sn[j] = sn[j] * ch - c[j] * sh;
-                        c[j] = cn;
-                    }
-                }
-                float4 o;
-                o.x = wss[0] > 1.17549435e-38f ? acc.x / wss[0] : acc.x;
-                o.y = wss[1] > 1.17549435e-38f ? acc.y / wss[1] : acc.y;
-                o.z = wss[2] > 1.17549435e-38f ? acc.z / wss[2] : acc.z;
-                o.w = wss[3] > 1.17549435e-38f ? acc.w / wss[3] : acc.w;
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-                *(float4*)(out + i0) = o;
-            }
-        }
-        __syncthreads();                                       // every reader of the old carry is done
-#pragma unroll
-        for (int it = 0; it < CARRY_IT; ++it) {
-            const int j = 4 * (threadIdx.x + it * BT);
-            if (j < NC) *(float4*)(carry + j) = nc[it];
-        }
-        __syncthreads();                                       // ... and F / x may be overwritten by the next group
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < BT / 64; ++i) mx = fmaxf(mx, red[i]);
-        partial[(long)sig * pl.nranges + rng] = mx;
+        lds_barrier();
     }
 }
 
@@ -643,6 +474,247 @@ __global__ __launch_bounds__(256) void istft_peak_normalize_kernel(float* audio,
         }
     } else {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) row[i] /= pk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-per-frame transforms (round 4; n_fft = 2048, the reference's default: preproc_mdb.py:202-204).
+// The radix-4 Stockham passes above spread one frame over a whole workgroup: 5 passes = 5 LDS round trips + 5 workgroup barriers per
+// group of frames, 2 waves per SIMD (72 KB of LDS per workgroup) -- measured latency-bound, 3x off its VALU time.  Here ONE WAVE owns
+// one frame: the 1024-point complex transform behind the real 2048-point one is 16 points per lane, factored 16 x 16 x 4:
+//     n = l + 64 r            radix-16 over the lane's registers r, twiddle W1024^(l k1)                      (no LDS)
+//     exchange 1              lane (k1, j) gets l = j + 4 r' of sub-transform k1            (LDS: 16 writes + 16 reads per lane)
+//     radix-16 over r', twiddle W64^(j k2); exchange 2: lane gets the four j of four (k1, k2) pairs           (16 + 16)
+//     radix-4 over j          lane l'' holds X[k1 + 16 k2 + 256 k3], k1 = l'' & 15, k2 = 4 q + (l'' >> 4), register 4 q + k3
+// Exchanges stay inside the wave's own 8.5 KB region: LDS operations of one wave complete in order, so no barrier and no wait sits
+// between a stage's writes and the next stage's reads; the four waves of a workgroup (four consecutive frames, so that row segments
+// are still written 16 B at a time) meet twice per group.  43.5 KB of LDS per workgroup: 3 workgroups = 12 waves per CU.
+// Layouts (pads 68 / 264) are bank-conflict-free for every access: tools/fit/lds_banks.py.
+constexpr int WREG = 1088;                                  // float2 per wave region: 16 sub-transforms x (64 + 4 pad)
+
+__device__ __forceinline__ void wave_order() {              // compiler-level ordering of a wave's own LDS traffic (no instruction)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int DIR> __device__ __forceinline__ void radix4(float2& a, float2& b, float2& c, float2& d) {
+    const float2 s0 = make_float2(a.x + c.x, a.y + c.y), s1 = make_float2(a.x - c.x, a.y - c.y);
+    const float2 s2 = make_float2(b.x + d.x, b.y + d.y), s3 = make_float2(b.x - d.x, b.y - d.y);
+    const float2 r3 = DIR > 0 ? make_float2(s3.y, -s3.x) : make_float2(-s3.y, s3.x);      // -/+ i s3
+    a = make_float2(s0.x + s2.x, s0.y + s2.y); b = make_float2(s1.x + r3.x, s1.y + r3.y);
+    c = make_float2(s0.x - s2.x, s0.y - s2.y); d = make_float2(s1.x - r3.x, s1.y - r3.y);
+}
+// v * (c -+ i s): the forward (DIR > 0) twiddle exp(-i theta) with cos = c, sin = s
+template <int DIR> __device__ __forceinline__ float2 tmul(float2 v, float c, float s) {
+    return DIR > 0 ? make_float2(__fmaf_rn(v.x, c, v.y * s), __fmaf_rn(v.y, c, -(v.x * s)))
+                   : make_float2(__fmaf_rn(v.x, c, -(v.y * s)), __fmaf_rn(v.y, c, v.x * s));
+}
+// 16-point transform of v[0..15] in place; the result X[k] sits at v[(k & 3) * 4 + (k >> 2)], i.e. v[i] = X[(i >> 2) + 4 (i & 3)]
+template <int DIR> __device__ __forceinline__ void radix16(float2 (&v)[16]) {
+    constexpr float C1 = 0.923879532511286756f, S1 = 0.382683432365089772f, R2 = 0.707106781186547524f;
+#pragma unroll
+    for (int r0 = 0; r0 < 4; ++r0) radix4<DIR>(v[r0], v[r0 + 4], v[r0 + 8], v[r0 + 12]);     // over r1: v[r0 + 4 q] = b[r0][q]
+    // twiddles w16^(r0 q), w16 = exp(-+ 2 pi i / 16)
+    v[5] = tmul<DIR>(v[5], C1, S1);   v[9] = tmul<DIR>(v[9], R2, R2);    v[13] = tmul<DIR>(v[13], S1, C1);     // r0 = 1: w, w^2, w^3
+    v[6] = tmul<DIR>(v[6], R2, R2);   v[10] = tmul<DIR>(v[10], 0.f, 1.f); v[14] = tmul<DIR>(v[14], -R2, R2);   // r0 = 2: w^2, w^4, w^6
+    v[7] = tmul<DIR>(v[7], S1, C1);   v[11] = tmul<DIR>(v[11], -R2, R2);  v[15] = tmul<DIR>(v[15], -C1, -S1);  // r0 = 3: w^3, w^6, w^9
+#pragma unroll
+    for (int q = 0; q < 4; ++q) radix4<DIR>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);   // over r0: v[4 q + s] = X[q + 4 s]
+}
+__device__ __forceinline__ int r16_out(int i) { return (i >> 2) + 4 * (i & 3); }      // index k of the value radix16 leaves in v[i]
+
+// T1[k1][l] = exp(-2 pi i l k1 / 1024), T2[k2][j] = exp(-2 pi i j k2 / 64): built once per workgroup
+__device__ void wave_fft_tables(float2* T1, float2* T2) {
+    for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+        float sn, cs;
+        sincospif(-2.0f * (float)((e & 63) * (e >> 6)) / 1024.0f, &sn, &cs);
+        T1[e] = make_float2(cs, sn);
+    }
+    for (int e = threadIdx.x; e < 64; e += blockDim.x) {
+        float sn, cs;
+        sincospif(-2.0f * (float)((e & 3) * (e >> 2)) / 64.0f, &sn, &cs);
+        T2[e] = make_float2(cs, sn);
+    }
+}
+
+// in: v[r] = z[lane + 64 r].  out: v[4 q + k3] = Z[k1 + 16 k2 + 256 k3], k1 = lane & 15, k2 = 4 q + (lane >> 4)   (unnormalised)
+template <int DIR>
+__device__ __forceinline__ void wave_fft1024(float2 (&v)[16], float2* reg, const float2* T1, const float2* T2, int lane) {
+    radix16<DIR>(v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k1 = r16_out(i);
+        if (k1) { const float2 w = T1[64 * k1 + lane]; v[i] = tmul<DIR>(v[i], w.x, -w.y); }   // (the table holds exp(-i theta): sin = -w.y)
+        reg[68 * k1 + lane] = v[i];
+    }
+    wave_order();
+    const int kb = lane >> 2, j = lane & 3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = reg[68 * kb + j + 4 * r];
+    wave_order();
+    radix16<DIR>(v);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k2 = r16_out(i);
+        if (k2) { const float2 w = T2[4 * k2 + j]; v[i] = tmul<DIR>(v[i], w.x, -w.y); }
+        reg[264 * j + kb + 16 * k2] = v[i];
+    }
+    wave_order();
+    const int k1 = lane & 15, kh = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) v[4 * q + jj] = reg[264 * jj + k1 + 16 * (4 * q + kh)];
+    wave_order();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) radix4<DIR>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+constexpr int WK_ITERS = 2;                                 // bin pairs (k, 1024 - k) per thread in the split phases: k = 1 + tid + 256 i
+
+// STFT, n_fft = 2048: wave w of a workgroup transforms frame t0 + w of the group; the split X[k] = E[k] + w^k O[k], the optional polar
+// epilogue and the 16 B row stores are the workgroup-wide phase of stft_frames_kernel, reading the four waves' spectra from LDS.
+template <bool CHUNKED>
+__global__ __launch_bounds__(256) void stft_w_kernel(const pg_stft_args a) {
+    __shared__ __attribute__((aligned(16))) float2 regs[SF][WREG];
+    __shared__ float2 T1[1024], T2[64];
+    constexpr int N = 2048, M = 1024;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = (a.n_frames + SF - 1) / SF, total = a.n_signals * groups;
+    wave_fft_tables(T1, T2);
+    float w0[16], w1[16], sc[WK_ITERS], ss[WK_ITERS];         // window at this lane's sample pairs m = lane + 64 r; split factors w^k
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int m = lane + 64 * r; w0[r] = hann(2 * m, N); w1[r] = hann(2 * m + 1, N); }
+#pragma unroll
+    for (int i = 0; i < WK_ITERS; ++i) sincospif(-(float)(1 + threadIdx.x + i * 256) / (float)M, &ss[i], &sc[i]);
+    const bool vec2 = !CHUNKED && ((a.hop | a.n_samples) & 1) == 0 && (((uintptr_t)a.y) & 7) == 0;   // sample pairs are 8 B aligned
+    const bool vec4 = (a.n_frames & 3) == 0 && (((uintptr_t)a.out) & 15) == 0;               // row segments are 16 B aligned
+    __syncthreads();
+    for (GroupWalk gw = group_walk(total); gw.g < gw.end; gw.g += gw.step) {
+        const int sig = gw.g / groups, t0 = (gw.g - sig * groups) * SF;
+        const int nfr = min(SF, a.n_frames - t0);
+        if (wave < nfr) {
+            const float* sgn; int lim;
+            if (CHUNKED) { const Src src = signal_src(a, sig); sgn = src.p; lim = src.lim; }
+            else { sgn = a.y + (long)sig * a.n_samples; lim = a.n_samples; }
+            auto at = [&](int q) { return (!CHUNKED || q < lim) ? sgn[q] : 0.f; };
+            const int start = (t0 + wave) * a.hop - M;                          // frame tap k sits at sample start + k
+            const bool inside = start >= 0 && start + N <= a.n_samples;
+            float2 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = start + 2 * (lane + 64 * r);
+                float v0, v1;
+                if (inside) {
+                    if (vec2) { const float2 t = *(const float2*)(sgn + p); v0 = t.x; v1 = t.y; }
+                    else { v0 = at(p); v1 = at(p + 1); }
+                } else { v0 = at(reflect_index(p, a.n_samples)); v1 = at(reflect_index(p + 1, a.n_samples)); }
+                v[r] = make_float2(v0 * w0[r], v1 * w1[r]);
+            }
+            wave_fft1024<1>(v, regs[wave], T1, T2, lane);
+            const int k1 = lane & 15, kh = lane >> 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k3 = 0; k3 < 4; ++k3) regs[wave][k1 + 16 * (4 * q + kh) + 256 * k3] = v[4 * q + k3];     // natural order
+        }
+        lds_barrier();
+        float* o_re = a.out + ((long)sig * 2 * M) * a.n_frames + t0;
+        float* o_im = o_re + (long)M * a.n_frames;
+        const bool vec = vec4 && nfr == SF;
+#pragma unroll
+        for (int i = 0; i < WK_ITERS; ++i) {                                  // bins k and M-k from Z[k], Z[M-k]; DC dropped
+            const int k = 1 + threadIdx.x + i * 256;                          // 1 .. 512
+            float rk[SF], ik[SF], rm[SF], im[SF];
+#pragma unroll
+            for (int f = 0; f < SF; ++f) {                                    // (frames past the end: never stored)
+                const float2 A = regs[f][k], B = regs[f][M - k];
+                const float2 E = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
+                const float2 O = make_float2(0.5f * (A.y + B.y), -0.5f * (A.x - B.x));
+                const float2 T = cmul(O, make_float2(sc[i], ss[i]));
+                rk[f] = E.x + T.x; ik[f] = E.y + T.y;
+                rm[f] = E.x - T.x; im[f] = T.y - E.y;
+            }
+            stft_store_row(a, o_re, o_im, k - 1, nfr, vec, rk, ik);
+            if (k != M - k) stft_store_row(a, o_re, o_im, M - k - 1, nfr, vec, rm, im);
+        }
+        if (threadIdx.x == 0) {                                               // Nyquist bin: X[M] = Re Z0 - Im Z0
+            float rn[SF], in[SF];
+#pragma unroll
+            for (int f = 0; f < SF; ++f) { const float2 Z0 = regs[f][0]; rn[f] = Z0.x - Z0.y; in[f] = 0.f; }
+            stft_store_row(a, o_re, o_im, M - 1, nfr, vec, rn, in);
+        }
+        lds_barrier();                                                        // the regions are the next group's work space
+    }
+}
+
+// ISTFT frames, n_fft = 2048: the workgroup builds the four half-length spectra Z_f[k] (natural order) together, then every wave
+// inverts its own frame and stores it windowed, 8 B per lane in runs of 128 B.
+__global__ __launch_bounds__(256) void istft_frames_w_kernel(const pg_istft_args a, float* frames) {
+    __shared__ __attribute__((aligned(16))) float2 regs[SF][WREG];
+    __shared__ float2 T1[1024], T2[64];
+    constexpr int N = 2048, M = 1024;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = (a.n_frames + SF - 1) / SF, total = a.n_signals * groups;
+    wave_fft_tables(T1, T2);
+    // window (times 1 / M) at the points this lane ends up with: m = k1 + 16 (4 q + kh) + 256 k3 in register 4 q + k3
+    const int k1 = lane & 15, kh = lane >> 4;
+    float wo0[16], wo1[16], sc[WK_ITERS], ss[WK_ITERS];
+    const float inv = 1.0f / (float)M;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k3 = 0; k3 < 4; ++k3) {
+            const int m = k1 + 16 * (4 * q + kh) + 256 * k3;
+            wo0[4 * q + k3] = inv * hann(2 * m, N); wo1[4 * q + k3] = inv * hann(2 * m + 1, N);
+        }
+#pragma unroll
+    for (int i = 0; i < WK_ITERS; ++i) sincospif((float)(1 + threadIdx.x + i * 256) / (float)M, &ss[i], &sc[i]);    // exp(+2 pi i k / n_fft)
+    const bool vec4 = (a.n_frames & 3) == 0 && ((a.a_bs | a.b_bs) & 3) == 0 && ((((uintptr_t)a.a) | ((uintptr_t)a.b)) & 15) == 0;
+    __syncthreads();
+    for (GroupWalk gw = group_walk(total); gw.g < gw.end; gw.g += gw.step) {
+        const int sig = gw.g / groups, t0 = (gw.g - sig * groups) * SF;
+        const int nfr = min(SF, a.n_frames - t0);
+        const float* pa = a.a + (long)sig * a.a_bs + t0;
+        const float* pb = a.b + (long)sig * a.b_bs + t0;
+        const bool vec = vec4 && nfr == SF;
+#pragma unroll
+        for (int i = 0; i < WK_ITERS; ++i) {                  // Z[k] = E[k] + i O[k] (see istft_frames4_kernel)
+            const int k = 1 + threadIdx.x + i * 256;
+            float2 Xk[SF], Xm[SF];
+            istft_row(a, pa, pb, k, nfr, vec, Xk);
+            istft_row(a, pa, pb, M - k, nfr, vec, Xm);
+#pragma unroll
+            for (int f = 0; f < SF; ++f) {
+                const float2 E = make_float2(0.5f * (Xk[f].x + Xm[f].x), 0.5f * (Xk[f].y - Xm[f].y));
+                const float2 D = make_float2(0.5f * (Xk[f].x - Xm[f].x), 0.5f * (Xk[f].y + Xm[f].y));
+                const float2 O = cmul(D, make_float2(sc[i], ss[i]));
+                regs[f][k] = make_float2(E.x - O.y, E.y + O.x);
+                if (k != M - k) regs[f][M - k] = make_float2(E.x + O.y, O.x - E.y);
+            }
+        }
+        if (threadIdx.x == 0) {
+            float2 Xn[SF];
+            istft_row(a, pa, pb, M, nfr, vec, Xn);
+#pragma unroll
+            for (int f = 0; f < SF; ++f) regs[f][0] = make_float2(0.5f * Xn[f].x, -0.5f * Xn[f].x);
+        }
+        lds_barrier();
+        if (wave < nfr) {
+            float2 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = regs[wave][lane + 64 * r];
+            wave_order();
+            wave_fft1024<-1>(v, regs[wave], T1, T2, lane);
+            float2* dst = (float2*)(frames + ((long)sig * a.n_frames + t0 + wave) * N);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k3 = 0; k3 < 4; ++k3) {
+                    const float2 z = v[4 * q + k3];
+                    dst[k1 + 16 * (4 * q + kh) + 256 * k3] = make_float2(z.x * wo0[4 * q + k3], z.y * wo1[4 * q + k3]);
+                }
+        }
+        lds_barrier();
     }
 }
 
@@ -814,6 +886,7 @@ bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // the batched kernels hold 2 x SF frames of n_fft/2 complex points plus the twiddle table: 72 KB at n_fft = 2048
 constexpr int BATCHED_MAX_NFFT = 2048;
 size_t batched_lds(int n_fft) { return (size_t)(2 * SF * (n_fft / 2) + 3 * tw_len(n_fft / 2)) * sizeof(float2); }
+int wave_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (3 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }   // 43.5 KB of LDS: 3 per CU
 int batched_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (2 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }
 // the attribute belongs to (function, CURRENT device): set on every call (a host-side table write), so a process that drives
 // several devices is served too and nothing is cached between calls
@@ -822,7 +895,7 @@ hipError_t batched_lds_ready() {
     hipError_t e = hipFuncSetAttribute((const void*)stft_frames_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_frames_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_frames4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 4 * CARRY_IT * BT * 4);
+
     return e;
 }
 
@@ -839,7 +912,11 @@ extern "C" int pg_stft(const pg_stft_args* a, void* stream) {
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     if (a->n_fft <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
-        if (a->chunk_start) hipLaunchKernelGGL(stft_frames_kernel<true>, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
+        if (a->n_fft == 2048) {        // one wave per frame (wave_fft1024)
+            if (a->chunk_start) hipLaunchKernelGGL(stft_w_kernel<true>, dim3((unsigned)wave_grid(total)), dim3(256), 0, (hipStream_t)stream, *a);
+            else hipLaunchKernelGGL(stft_w_kernel<false>, dim3((unsigned)wave_grid(total)), dim3(256), 0, (hipStream_t)stream, *a);
+        }
+        else if (a->chunk_start) hipLaunchKernelGGL(stft_frames_kernel<true>, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
         else hipLaunchKernelGGL(stft_frames_kernel<false>, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
     } else {
         const size_t lds = (size_t)(2 * a->n_fft + a->n_fft / 2) * sizeof(float2);
@@ -864,15 +941,9 @@ static int64_t ola_partial_bytes(const pg_istft_args* a) {
     return (b + 255) / 256 * 256;
 }
 
-static int64_t fused_partial_bytes(const pg_istft_args* a, const IstftPlan& pl) {
-    return ((int64_t)a->n_signals * pl.nranges * (int64_t)sizeof(float) + 255) / 256 * 256;
-}
-
 extern "C" int64_t pg_workspace_bytes_istft(const pg_istft_args* a) {
     if (!a) return 0;
-    const IstftPlan pl = istft_plan(a->n_signals, a->bins, a->n_frames, a->hop, a->single_frame, pg_cu_count());
-    // fused path: [256 B reserved][per-workgroup peaks]; three-kernel path: [256 B][per-workgroup peaks of the overlap-add][frames]
-    if (pl.fused) return 256 + fused_partial_bytes(a, pl);
+    // [256 B reserved][per-workgroup peaks of the overlap-add, padded to 256 B][frames]
     return 256 + ola_partial_bytes(a) + (int64_t)a->n_signals * a->n_frames * 2 * a->bins * (int64_t)sizeof(float);
 }
 
@@ -884,29 +955,22 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
     if (a->workspace_bytes < pg_workspace_bytes_istft(a)) return pg_fail(PG_ERR_WORKSPACE, "istft: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)((char*)a->workspace + 256);
+    float* frames = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));
     hipError_t e;
     if ((e = batched_lds_ready()) != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
-    const int len = a->hop * (a->n_frames - 1);
-    int bx = (len / 4 + 255) / 256; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
-    const IstftPlan pl = istft_plan(a->n_signals, a->bins, a->n_frames, a->hop, a->single_frame, pg_cu_count());
-    if (pl.fused) {
-        const int total = a->n_signals * pl.nranges, grid = 8 * ((total + 7) / 8);
-        const size_t lds = batched_lds(N) + (size_t)(N - a->hop) * sizeof(float);
-        hipLaunchKernelGGL(istft_fused_kernel, dim3((unsigned)grid), dim3(BT), lds, st, *a, partial, pl);
-        if (a->normalize) hipLaunchKernelGGL(istft_peak_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const float*)partial, pl.nranges);
-        e = hipGetLastError();
-        return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
-    }
-    float* frames = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));
     if (N <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
-        hipLaunchKernelGGL(istft_frames4_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(N), st, *a, frames);
+        if (N == 2048) hipLaunchKernelGGL(istft_frames_w_kernel, dim3((unsigned)wave_grid(total)), dim3(256), 0, st, *a, frames);
+        else hipLaunchKernelGGL(istft_frames4_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(N), st, *a, frames);
     } else {
         const size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
         hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)(a->n_signals * a->n_frames)), dim3(FFT_THREADS), lds, st, *a, frames);
     }
+    const int len = a->hop * (a->n_frames - 1);
     const int nblk = ola_blocks(a);
     hipLaunchKernelGGL(istft_ola4_kernel, dim3(nblk, a->n_signals), dim3(256), 0, st, *a, (const float*)frames, partial);
+    int bx = (len / 4 + 255) / 256; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
+    // the peak over the overlap-add's per-workgroup peaks and the division by it are ONE launch (round 3: two)
     if (a->normalize) hipLaunchKernelGGL(istft_peak_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const float*)partial, nblk);
     e = hipGetLastError();
     return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
