@@ -17,6 +17,9 @@
 #ifndef PG_STFT_ABL
 #define PG_STFT_ABL 0
 #endif
+#ifndef PG_W_ABL         /* dev-only timing ablations of stft_w_kernel / istft_frames_w_kernel (wrong results): 1 no sample / row loads, */
+#define PG_W_ABL 0       /* 2 no transform, 4 no global stores, 8 no workgroup-wide phase at all                                          */
+#endif
 
 
 namespace {
@@ -220,7 +223,7 @@ __device__ __forceinline__ void stft_store_row(const pg_stft_args& a, float* o_r
     }
     float* pr = o_re + row * a.n_frames;
     float* pi = o_im + row * a.n_frames;
-#if PG_STFT_ABL == 1    /* dev-only: everything but the global stores (values kept alive) */
+#if PG_STFT_ABL == 1 || (PG_W_ABL & 4)   /* dev-only: everything but the global stores (values kept alive) */
     asm volatile("" :: "v"(re[0]), "v"(re[1]), "v"(re[2]), "v"(re[3]), "v"(im[0]), "v"(im[1]), "v"(im[2]), "v"(im[3]), "v"(pr), "v"(pi));
     return;
 #endif
@@ -487,8 +490,9 @@ __global__ __launch_bounds__(256) void istft_peak_normalize_kernel(float* audio,
 //     radix-16 over r', twiddle W64^(j k2); exchange 2: lane gets the four j of four (k1, k2) pairs           (16 + 16)
 //     radix-4 over j          lane l'' holds X[k1 + 16 k2 + 256 k3], k1 = l'' & 15, k2 = 4 q + (l'' >> 4), register 4 q + k3
 // Exchanges stay inside the wave's own 8.5 KB region: LDS operations of one wave complete in order, so no barrier and no wait sits
-// between a stage's writes and the next stage's reads; the four waves of a workgroup (four consecutive frames, so that row segments
-// are still written 16 B at a time) meet twice per group.  43.5 KB of LDS per workgroup: 3 workgroups = 12 waves per CU.
+// between a stage's writes and the next stage's reads; the eight waves of a workgroup (eight consecutive frames: rows of the
+// (bins, frames) layout are touched 32 B at a time -- at 16 B the row stores alone were 28 of 74 us, one L2 request per 16 B piece)
+// meet twice per group.  78.3 KB of LDS per workgroup: 2 workgroups = 16 waves per CU.
 // Layouts (pads 68 / 264) are bank-conflict-free for every access: tools/fit/lds_banks.py.
 constexpr int WREG = 1088;                                  // float2 per wave region: 16 sub-transforms x (64 + 4 pad)
 
@@ -569,48 +573,116 @@ __device__ __forceinline__ void wave_fft1024(float2 (&v)[16], float2* reg, const
     for (int q = 0; q < 4; ++q) radix4<DIR>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
-constexpr int WK_ITERS = 2;                                 // bin pairs (k, 1024 - k) per thread in the split phases: k = 1 + tid + 256 i
+// Periodic Hann window of length 2048 at the sample pair (2 m, 2 m + 1) from (cos, sin) of theta_m = 2 pi m / 1024, which the lanes
+// compose from a per-lane base angle and compile-time rotations (multiples of pi / 8 and of pi / 2): 32 window values per frame
+// cost ~130 flops instead of 32 registers per lane held for the whole kernel.
+constexpr float W8C[16] = {1.f, 0.923879532511286756f, 0.707106781186547524f, 0.382683432365089772f, 0.f, -0.382683432365089772f,
+                           -0.707106781186547524f, -0.923879532511286756f, -1.f, -0.923879532511286756f, -0.707106781186547524f,
+                           -0.382683432365089772f, 0.f, 0.382683432365089772f, 0.707106781186547524f, 0.923879532511286756f};
+constexpr float W8S[16] = {0.f, 0.382683432365089772f, 0.707106781186547524f, 0.923879532511286756f, 1.f, 0.923879532511286756f,
+                           0.707106781186547524f, 0.382683432365089772f, 0.f, -0.382683432365089772f, -0.707106781186547524f,
+                           -0.923879532511286756f, -1.f, -0.923879532511286756f, -0.707106781186547524f, -0.382683432365089772f};
+__device__ __forceinline__ void hann_pair(float c, float s, float& w0, float& w1) {       // (c, s) = (cos, sin) theta_m
+    constexpr float CD = 0.999995293809576172f, SD = 0.00306795676296597627f;             // cos, sin (pi / 1024): half a pair further
+    w0 = 0.5f - 0.5f * c;
+    w1 = 0.5f - 0.5f * __fmaf_rn(c, CD, -(s * SD));
+}
 
-// STFT, n_fft = 2048: wave w of a workgroup transforms frame t0 + w of the group; the split X[k] = E[k] + w^k O[k], the optional polar
-// epilogue and the 16 B row stores are the workgroup-wide phase of stft_frames_kernel, reading the four waves' spectra from LDS.
+constexpr int NW = 8;                                       // waves = frames per workgroup: row segments of 8 frames (32 B)
+constexpr int WT = NW * 64;                                 // threads; thread tid owns the bin pair (k, 1024 - k), k = 1 + tid
+
+// dynamic LDS of the wave-per-frame kernels: NW wave regions + T1 + T2 (78.3 KB: two workgroups = 16 waves per CU)
+constexpr size_t WAVE_LDS = (size_t)(NW * WREG + 1024 + 64) * sizeof(float2);
+
+// one output row, 4 of the group's 8 frames (half = 0 / 1): as stft_store_row
+__device__ __forceinline__ void stft_store_row4(const pg_stft_args& a, float* o_re, float* o_im, long row, int half, int nfr, bool vec,
+                                                float (&re)[4], float (&im)[4]) {
+    if (a.polar) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {                         // (fenced: measured 87 us against 91-93 with the four chains interleaved)
+            const float r = re[f], i = im[f];
+            pg_polar_one(r, i, 1, re[f], im[f]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float* pr = o_re + row * a.n_frames + 4 * half;
+    float* pi = o_im + row * a.n_frames + 4 * half;
+#if (PG_W_ABL & 4)
+    asm volatile("" :: "v"(re[0]), "v"(re[1]), "v"(re[2]), "v"(re[3]), "v"(im[0]), "v"(im[1]), "v"(im[2]), "v"(im[3]), "v"(pr), "v"(pi));
+    return;
+#endif
+    if (vec) {
+        *(float4*)pr = make_float4(re[0], re[1], re[2], re[3]);
+        *(float4*)pi = make_float4(im[0], im[1], im[2], im[3]);
+    } else {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (4 * half + f < nfr) { pr[f] = re[f]; pi[f] = im[f]; }
+    }
+}
+
+// STFT, n_fft = 2048: wave w of a workgroup transforms frame t0 + w of its group of NW frames; the split X[k] = E[k] + w^k O[k], the
+// optional polar epilogue and the row stores (two 16 B pieces = 32 B per row and workgroup) are the workgroup-wide phase, reading the
+// waves' spectra from LDS.
 template <bool CHUNKED>
-__global__ __launch_bounds__(256) void stft_w_kernel(const pg_stft_args a) {
-    __shared__ __attribute__((aligned(16))) float2 regs[SF][WREG];
-    __shared__ float2 T1[1024], T2[64];
+__global__ __launch_bounds__(WT, CHUNKED ? 2 : 4) void stft_w_kernel(const pg_stft_args a) {
+    extern __shared__ __attribute__((aligned(16))) float2 wsm[];
+    float2 (*regs)[WREG] = (float2 (*)[WREG])wsm;
+    float2* T1 = wsm + NW * WREG; float2* T2 = T1 + 1024;
     constexpr int N = 2048, M = 1024;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int groups = (a.n_frames + SF - 1) / SF, total = a.n_signals * groups;
+    const int groups = (a.n_frames + NW - 1) / NW, total = a.n_signals * groups;
     wave_fft_tables(T1, T2);
-    float w0[16], w1[16], sc[WK_ITERS], ss[WK_ITERS];         // window at this lane's sample pairs m = lane + 64 r; split factors w^k
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { const int m = lane + 64 * r; w0[r] = hann(2 * m, N); w1[r] = hann(2 * m + 1, N); }
-#pragma unroll
-    for (int i = 0; i < WK_ITERS; ++i) sincospif(-(float)(1 + threadIdx.x + i * 256) / (float)M, &ss[i], &sc[i]);
+    float cb, sb, sc, ss;                                     // (cos, sin)(2 pi lane / 1024): base of this lane's window angles; split factor w^k
+    sincospif(2.0f * (float)lane / 1024.0f, &sb, &cb);
+    float sc2, ss2;                                           // split factors of this thread's two bin pairs k = 1 + (tid >> 1) + 256 i
+    sincospif(-(float)(1 + (int)(threadIdx.x >> 1)) / (float)M, &ss, &sc);
+    sincospif(-(float)(257 + (int)(threadIdx.x >> 1)) / (float)M, &ss2, &sc2);
     const bool vec2 = !CHUNKED && ((a.hop | a.n_samples) & 1) == 0 && (((uintptr_t)a.y) & 7) == 0;   // sample pairs are 8 B aligned
     const bool vec4 = (a.n_frames & 3) == 0 && (((uintptr_t)a.out) & 15) == 0;               // row segments are 16 B aligned
+    // This wave's frame of group g as RAW sample pairs v[r] = (y[2 m], y[2 m + 1]), m = lane + 64 r (reflect padding by index math: the
+    // bit-exact part of the contract).  Issued one group AHEAD, into the registers the finished transform has just vacated, so the
+    // samples travel while the workgroup splits, converts and stores the current group.
+    float2 v[16];
+    auto load_frame = [&](int g) {
+        const int sig = g / groups, t0 = (g - sig * groups) * NW;
+        if (wave >= min(NW, a.n_frames - t0)) return;
+        const float* sgn; int lim;
+        if (CHUNKED) { const Src src = signal_src(a, sig); sgn = src.p; lim = src.lim; }
+        else { sgn = a.y + (long)sig * a.n_samples; lim = a.n_samples; }
+        auto at = [&](int q) { return (!CHUNKED || q < lim) ? sgn[q] : 0.f; };
+        const int start = (t0 + wave) * a.hop - M;                              // frame tap k sits at sample start + k
+        const bool inside = start >= 0 && start + N <= a.n_samples;
+        int lo = lane;
+        asm volatile("" : "+v"(lo));                          // (opaque: keeps 16 per-lane sample offsets out of the loop-invariant registers)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = start + 2 * (lo + 64 * r);
+            float v0, v1;
+            if (PG_W_ABL & 1) { v0 = (float)p; v1 = 1.f; }
+            else if (inside) {
+                if (vec2) { const float2 t = *(const float2*)(sgn + p); v0 = t.x; v1 = t.y; }
+                else { v0 = at(p); v1 = at(p + 1); }
+            } else { v0 = at(reflect_index(p, a.n_samples)); v1 = at(reflect_index(p + 1, a.n_samples)); }
+            v[r] = make_float2(v0, v1);
+        }
+    };
     __syncthreads();
-    for (GroupWalk gw = group_walk(total); gw.g < gw.end; gw.g += gw.step) {
-        const int sig = gw.g / groups, t0 = (gw.g - sig * groups) * SF;
-        const int nfr = min(SF, a.n_frames - t0);
+    GroupWalk gw = group_walk(total);
+    if (gw.g < gw.end) load_frame(gw.g);
+    for (; gw.g < gw.end; gw.g += gw.step) {
+        const int sig = gw.g / groups, t0 = (gw.g - sig * groups) * NW;
+        const int nfr = min(NW, a.n_frames - t0);
         if (wave < nfr) {
-            const float* sgn; int lim;
-            if (CHUNKED) { const Src src = signal_src(a, sig); sgn = src.p; lim = src.lim; }
-            else { sgn = a.y + (long)sig * a.n_samples; lim = a.n_samples; }
-            auto at = [&](int q) { return (!CHUNKED || q < lim) ? sgn[q] : 0.f; };
-            const int start = (t0 + wave) * a.hop - M;                          // frame tap k sits at sample start + k
-            const bool inside = start >= 0 && start + N <= a.n_samples;
-            float2 v[16];
+            float cbo = cb, sbo = sb;
+            asm volatile("" : "+v"(cbo), "+v"(sbo));          // (opaque: or the 32 window values are hoisted out of the loop and spilled)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int p = start + 2 * (lane + 64 * r);
-                float v0, v1;
-                if (inside) {
-                    if (vec2) { const float2 t = *(const float2*)(sgn + p); v0 = t.x; v1 = t.y; }
-                    else { v0 = at(p); v1 = at(p + 1); }
-                } else { v0 = at(reflect_index(p, a.n_samples)); v1 = at(reflect_index(p + 1, a.n_samples)); }
-                v[r] = make_float2(v0 * w0[r], v1 * w1[r]);
+                float w0, w1;                                                   // m = lane + 64 r: theta = base + r pi / 8
+                hann_pair(__fmaf_rn(cbo, W8C[r], -(sbo * W8S[r])), __fmaf_rn(sbo, W8C[r], cbo * W8S[r]), w0, w1);
+                v[r] = make_float2(v[r].x * w0, v[r].y * w1);
             }
-            wave_fft1024<1>(v, regs[wave], T1, T2, lane);
+            if (!(PG_W_ABL & 2)) wave_fft1024<1>(v, regs[wave], T1, T2, lane);
             const int k1 = lane & 15, kh = lane >> 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -618,85 +690,96 @@ __global__ __launch_bounds__(256) void stft_w_kernel(const pg_stft_args a) {
                 for (int k3 = 0; k3 < 4; ++k3) regs[wave][k1 + 16 * (4 * q + kh) + 256 * k3] = v[4 * q + k3];     // natural order
         }
         lds_barrier();
+        if (gw.g + gw.step < gw.end) load_frame(gw.g + gw.step);              // (v is free: the spectra are in LDS)
         float* o_re = a.out + ((long)sig * 2 * M) * a.n_frames + t0;
         float* o_im = o_re + (long)M * a.n_frames;
-        const bool vec = vec4 && nfr == SF;
+        if (PG_W_ABL & 8) { lds_barrier(); continue; }
+        // Lanes 2 i and 2 i + 1 take the two 16 B halves of the SAME rows, so a wave's store instruction covers 32 rows x 32 contiguous
+        // bytes (one L2 request per row instead of two); a thread does two bin pairs: k = 1 + (tid >> 1) + 256 i.
+        int tid_o = threadIdx.x;
+        asm volatile("" : "+v"(tid_o));                       // (opaque: the row addresses below are computed here, not carried across the barrier)
+        const int half = tid_o & 1;
+        if (4 * half < nfr) {
+            const bool vec = vec4 && 4 * half + 4 <= nfr;
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {                                     // bins k and M-k from Z[k], Z[M-k]; DC dropped
+                const int k = 1 + (tid_o >> 1) + 256 * i;                     // 1 .. 512
+                const float sn = i ? ss2 : ss, cs = i ? sc2 : sc;
+                float rk[4], ik[4], rm[4], im[4];
 #pragma unroll
-        for (int i = 0; i < WK_ITERS; ++i) {                                  // bins k and M-k from Z[k], Z[M-k]; DC dropped
-            const int k = 1 + threadIdx.x + i * 256;                          // 1 .. 512
-            float rk[SF], ik[SF], rm[SF], im[SF];
+                for (int f = 0; f < 4; ++f) {                                 // (frames past the end: never stored)
+                    const float2 A = regs[4 * half + f][k], B = regs[4 * half + f][M - k];
+                    const float2 E = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
+                    const float2 O = make_float2(0.5f * (A.y + B.y), -0.5f * (A.x - B.x));
+                    const float2 T = cmul(O, make_float2(cs, sn));
+                    rk[f] = E.x + T.x; ik[f] = E.y + T.y;
+                    rm[f] = E.x - T.x; im[f] = T.y - E.y;
+                }
+                stft_store_row4(a, o_re, o_im, k - 1, half, nfr, vec, rk, ik);
+                if (k != M - k) stft_store_row4(a, o_re, o_im, M - k - 1, half, nfr, vec, rm, im);
+                else {                                                        // the self-paired threads also own the Nyquist bin:
+                    float rn[4], in[4];                                       // X[M] = Re Z0 - Im Z0
 #pragma unroll
-            for (int f = 0; f < SF; ++f) {                                    // (frames past the end: never stored)
-                const float2 A = regs[f][k], B = regs[f][M - k];
-                const float2 E = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
-                const float2 O = make_float2(0.5f * (A.y + B.y), -0.5f * (A.x - B.x));
-                const float2 T = cmul(O, make_float2(sc[i], ss[i]));
-                rk[f] = E.x + T.x; ik[f] = E.y + T.y;
-                rm[f] = E.x - T.x; im[f] = T.y - E.y;
+                    for (int f = 0; f < 4; ++f) { const float2 Z0 = regs[4 * half + f][0]; rn[f] = Z0.x - Z0.y; in[f] = 0.f; }
+                    stft_store_row4(a, o_re, o_im, M - 1, half, nfr, vec, rn, in);
+                }
             }
-            stft_store_row(a, o_re, o_im, k - 1, nfr, vec, rk, ik);
-            if (k != M - k) stft_store_row(a, o_re, o_im, M - k - 1, nfr, vec, rm, im);
-        }
-        if (threadIdx.x == 0) {                                               // Nyquist bin: X[M] = Re Z0 - Im Z0
-            float rn[SF], in[SF];
-#pragma unroll
-            for (int f = 0; f < SF; ++f) { const float2 Z0 = regs[f][0]; rn[f] = Z0.x - Z0.y; in[f] = 0.f; }
-            stft_store_row(a, o_re, o_im, M - 1, nfr, vec, rn, in);
         }
         lds_barrier();                                                        // the regions are the next group's work space
     }
 }
 
-// ISTFT frames, n_fft = 2048: the workgroup builds the four half-length spectra Z_f[k] (natural order) together, then every wave
-// inverts its own frame and stores it windowed, 8 B per lane in runs of 128 B.
-__global__ __launch_bounds__(256) void istft_frames_w_kernel(const pg_istft_args a, float* frames) {
-    __shared__ __attribute__((aligned(16))) float2 regs[SF][WREG];
-    __shared__ float2 T1[1024], T2[64];
+// ISTFT frames, n_fft = 2048: the workgroup builds the NW half-length spectra Z_f[k] (natural order) together -- rows are read as
+// two 16 B pieces (32 B per row and workgroup) --, then every wave inverts its own frame and stores it windowed, 8 B per lane in
+// runs of 128 B.
+__global__ __launch_bounds__(WT, 4) void istft_frames_w_kernel(const pg_istft_args a, float* frames) {
+    extern __shared__ __attribute__((aligned(16))) float2 wsm[];
+    float2 (*regs)[WREG] = (float2 (*)[WREG])wsm;
+    float2* T1 = wsm + NW * WREG; float2* T2 = T1 + 1024;
     constexpr int N = 2048, M = 1024;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int groups = (a.n_frames + SF - 1) / SF, total = a.n_signals * groups;
+    const int groups = (a.n_frames + NW - 1) / NW, total = a.n_signals * groups;
     wave_fft_tables(T1, T2);
-    // window (times 1 / M) at the points this lane ends up with: m = k1 + 16 (4 q + kh) + 256 k3 in register 4 q + k3
-    const int k1 = lane & 15, kh = lane >> 4;
-    float wo0[16], wo1[16], sc[WK_ITERS], ss[WK_ITERS];
+    // window (times 1 / M) at the points this lane ends up with: m = k1 + 16 (4 q + kh) + 256 k3 in register 4 q + k3,
+    // k1 = lane & 15, kh = lane >> 4, i.e. k1 + 16 kh = lane
+    float cb, sb, sc, ss;                                     // (cos, sin)(2 pi lane / 1024): theta_m = base + q pi / 8 + k3 pi / 2
+    sincospif(2.0f * (float)lane / 1024.0f, &sb, &cb);
     const float inv = 1.0f / (float)M;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int k3 = 0; k3 < 4; ++k3) {
-            const int m = k1 + 16 * (4 * q + kh) + 256 * k3;
-            wo0[4 * q + k3] = inv * hann(2 * m, N); wo1[4 * q + k3] = inv * hann(2 * m + 1, N);
-        }
-#pragma unroll
-    for (int i = 0; i < WK_ITERS; ++i) sincospif((float)(1 + threadIdx.x + i * 256) / (float)M, &ss[i], &sc[i]);    // exp(+2 pi i k / n_fft)
+    float sc2, ss2;                                           // exp(+2 pi i k / n_fft) of this thread's two bin pairs k = 1 + (tid >> 1) + 256 i
+    sincospif((float)(1 + (int)(threadIdx.x >> 1)) / (float)M, &ss, &sc);
+    sincospif((float)(257 + (int)(threadIdx.x >> 1)) / (float)M, &ss2, &sc2);
     const bool vec4 = (a.n_frames & 3) == 0 && ((a.a_bs | a.b_bs) & 3) == 0 && ((((uintptr_t)a.a) | ((uintptr_t)a.b)) & 15) == 0;
+    // (A prefetch of the next group's rows during the transforms needs 32 more registers than two workgroups per CU leave: measured
+    // 151 us at one workgroup per CU with it against 125 us without.)  Lanes 2 i and 2 i + 1 read the two 16 B halves of the same rows (a wave's
+    // load instruction covers 32 rows x 32 contiguous bytes); a thread does two bin pairs: k = 1 + (tid >> 1) + 256 i.
+    const int half = threadIdx.x & 1;
     __syncthreads();
     for (GroupWalk gw = group_walk(total); gw.g < gw.end; gw.g += gw.step) {
-        const int sig = gw.g / groups, t0 = (gw.g - sig * groups) * SF;
-        const int nfr = min(SF, a.n_frames - t0);
-        const float* pa = a.a + (long)sig * a.a_bs + t0;
-        const float* pb = a.b + (long)sig * a.b_bs + t0;
-        const bool vec = vec4 && nfr == SF;
+        const int sig = gw.g / groups, t0 = (gw.g - sig * groups) * NW;
+        const int nfr = min(NW, a.n_frames - t0);
+        const int n4 = nfr - 4 * half;
+        if (n4 > 0) {                                         // Z[k] = E[k] + i O[k] (see istft_frames4_kernel)
+            const float* pa = a.a + (long)sig * a.a_bs + t0 + 4 * half;
+            const float* pb = a.b + (long)sig * a.b_bs + t0 + 4 * half;
+            const bool vec = vec4 && n4 >= 4;
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {
+                const int k = 1 + (int)(threadIdx.x >> 1) + 256 * i;
+                const float sn = i ? ss2 : ss, cs = i ? sc2 : sc;
+                float2 Xk[SF], Xm[SF];
+                istft_row(a, pa, pb, k, n4, vec, Xk);
+                istft_row(a, pa, pb, k == M - k ? M : M - k, n4, vec, Xm);   // (the self-paired threads read the Nyquist row here)
 #pragma unroll
-        for (int i = 0; i < WK_ITERS; ++i) {                  // Z[k] = E[k] + i O[k] (see istft_frames4_kernel)
-            const int k = 1 + threadIdx.x + i * 256;
-            float2 Xk[SF], Xm[SF];
-            istft_row(a, pa, pb, k, nfr, vec, Xk);
-            istft_row(a, pa, pb, M - k, nfr, vec, Xm);
-#pragma unroll
-            for (int f = 0; f < SF; ++f) {
-                const float2 E = make_float2(0.5f * (Xk[f].x + Xm[f].x), 0.5f * (Xk[f].y - Xm[f].y));
-                const float2 D = make_float2(0.5f * (Xk[f].x - Xm[f].x), 0.5f * (Xk[f].y + Xm[f].y));
-                const float2 O = cmul(D, make_float2(sc[i], ss[i]));
-                regs[f][k] = make_float2(E.x - O.y, E.y + O.x);
-                if (k != M - k) regs[f][M - k] = make_float2(E.x + O.y, O.x - E.y);
+                for (int f = 0; f < 4; ++f) {
+                    const float2 Xo = k == M - k ? Xk[f] : Xm[f];
+                    const float2 E = make_float2(0.5f * (Xk[f].x + Xo.x), 0.5f * (Xk[f].y - Xo.y));
+                    const float2 D = make_float2(0.5f * (Xk[f].x - Xo.x), 0.5f * (Xk[f].y + Xo.y));
+                    const float2 O = cmul(D, make_float2(cs, sn));
+                    regs[4 * half + f][k] = make_float2(E.x - O.y, E.y + O.x);
+                    if (k != M - k) regs[4 * half + f][M - k] = make_float2(E.x + O.y, O.x - E.y);
+                    else regs[4 * half + f][0] = make_float2(0.5f * Xm[f].x, -0.5f * Xm[f].x);      // Z[0]: X[0] = 0, X[M] real
+                }
             }
-        }
-        if (threadIdx.x == 0) {
-            float2 Xn[SF];
-            istft_row(a, pa, pb, M, nfr, vec, Xn);
-#pragma unroll
-            for (int f = 0; f < SF; ++f) regs[f][0] = make_float2(0.5f * Xn[f].x, -0.5f * Xn[f].x);
         }
         lds_barrier();
         if (wave < nfr) {
@@ -704,19 +787,223 @@ __global__ __launch_bounds__(256) void istft_frames_w_kernel(const pg_istft_args
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = regs[wave][lane + 64 * r];
             wave_order();
-            wave_fft1024<-1>(v, regs[wave], T1, T2, lane);
+            if (!(PG_W_ABL & 2)) wave_fft1024<-1>(v, regs[wave], T1, T2, lane);
+            int lo = lane;
+            asm volatile("" : "+v"(lo));                      // (opaque: keeps the store addresses out of the loop-invariant registers)
+            const int k1 = lo & 15, kh = lo >> 4;
             float2* dst = (float2*)(frames + ((long)sig * a.n_frames + t0 + wave) * N);
+            float cbo = cb, sbo = sb;
+            asm volatile("" : "+v"(cbo), "+v"(sbo));          // (opaque: or the 32 window values are hoisted out of the loop)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                const float cq = __fmaf_rn(cbo, W8C[q], -(sbo * W8S[q])), sq = __fmaf_rn(sbo, W8C[q], cbo * W8S[q]);     // + q pi / 8
 #pragma unroll
                 for (int k3 = 0; k3 < 4; ++k3) {
+                    const float c = k3 == 0 ? cq : k3 == 1 ? -sq : k3 == 2 ? -cq : sq;                              // + k3 pi / 2
+                    const float sn = k3 == 0 ? sq : k3 == 1 ? cq : k3 == 2 ? -sq : -cq;
+                    float w0, w1;
+                    hann_pair(c, sn, w0, w1);
                     const float2 z = v[4 * q + k3];
-                    dst[k1 + 16 * (4 * q + kh) + 256 * k3] = make_float2(z.x * wo0[4 * q + k3], z.y * wo1[4 * q + k3]);
+                    dst[k1 + 16 * (4 * q + kh) + 256 * k3] = make_float2(z.x * (inv * w0), z.y * (inv * w1));
                 }
+            }
         }
         lds_barrier();
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ISTFT at n_fft = 2048, hop = 512 with the overlap-add INSIDE the transform kernel (round 4): a workgroup's eight windowed frames
+// never leave LDS.  Of the 8 hop + (n_fft - hop) output positions they touch, blocks 3..7 (of 512 samples) are complete and are
+// finalised on the spot (window-sum-square division, n_fft / 2 trim, peak, one 16 B store per lane); blocks 0..2 ("head") still miss
+// the previous group's last three frames and blocks 8..10 ("tail") are this group's share of the next group's head: the head is
+// stored to the audio buffer as a partial sum, the tail to a small workspace (6 KB per group), and a seam kernel adds the two --
+// exactly two addends per sample, in a fixed order -- and finalises those 3 / 8 of the samples.  The 134 MB frame workspace of the
+// three-kernel path (written, then read again by the overlap-add) is gone: 134 + 33 + 12.5 MB in the main kernel, 37 MB at the seams.
+constexpr int OW_HOP = 512, OW_COVER = 4, OW_HB = OW_COVER - 1;       // hop; frames covering a sample; head / tail blocks per group
+
+struct WssCtx { float sd, cd, sh, ch; float iw[4]; };
+// a thread's constants: window rotations by one sample / one hop, and the interior window-sum-square of its four positions
+// (positions 4 e + j with e = tid + 512 i: the residue mod hop does not depend on i because hop divides 2048)
+__device__ __forceinline__ WssCtx wss_ctx(int first_pos, int N, int hop) {
+    WssCtx c;
+    sincospif(2.0f / (float)N, &c.sd, &c.cd);
+    sincospif(2.0f * (float)hop / (float)N, &c.sh, &c.ch);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+        for (int t = 0; t < N / hop; ++t) { const float w = hann((first_pos + j) % hop + t * hop, N); acc += w * w; }
+        c.iw[j] = acc;
+    }
+    return c;
+}
+// four consecutive output samples at padded position ip (multiple of 4): divide the overlap-added sums by librosa's
+// window_sumsquare over the frames that exist there (utils.py:40, librosa.istft); returns max |y|
+__device__ __forceinline__ float ola_finalize(float4& acc, int ip, int N, int hop, int n_frames, const WssCtx& c) {
+    int t_hi = ip / hop; if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+    int t_lo = (ip - N + hop) / hop; if (ip - N + 1 <= 0) t_lo = 0;
+    float wss[4];
+    if (t_hi - t_lo + 1 == N / hop) {                                       // interior: the thread's constants
+        wss[0] = c.iw[0]; wss[1] = c.iw[1]; wss[2] = c.iw[2]; wss[3] = c.iw[3];
+    } else {                                                                // ends of the signal: by rotation
+        float cs[4], sn[4];
+        wss[0] = wss[1] = wss[2] = wss[3] = 0.f;
+        sincospif(2.0f * (float)(ip - t_lo * hop) / (float)N, &sn[0], &cs[0]);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) { cs[j] = cs[j - 1] * c.cd - sn[j - 1] * c.sd; sn[j] = sn[j - 1] * c.cd + cs[j - 1] * c.sd; }
+        for (int t = t_lo; t <= t_hi; ++t) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float w = 0.5f - 0.5f * cs[j];
+                wss[j] += w * w;
+                const float cn = cs[j] * c.ch + sn[j] * c.sh;               // the next frame sees this sample hop taps earlier
+                sn[j] = sn[j] * c.ch - cs[j] * c.sh;
+                cs[j] = cn;
+            }
+        }
+    }
+    acc.x = wss[0] > 1.17549435e-38f ? acc.x / wss[0] : acc.x;
+    acc.y = wss[1] > 1.17549435e-38f ? acc.y / wss[1] : acc.y;
+    acc.z = wss[2] > 1.17549435e-38f ? acc.z / wss[2] : acc.z;
+    acc.w = wss[3] > 1.17549435e-38f ? acc.w / wss[3] : acc.w;
+    return fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+}
+
+// partial[] layout of this path, per signal: [groups] peaks of the main kernel's finalised samples, then [groups] peaks of the seams
+__global__ __launch_bounds__(WT, 4) void istft_ola_w_kernel(const pg_istft_args a, float* tails, float* partial) {
+    extern __shared__ __attribute__((aligned(16))) float2 wsm[];
+    __shared__ float red[NW];
+    float2 (*regs)[WREG] = (float2 (*)[WREG])wsm;
+    float2* T1 = wsm + NW * WREG; float2* T2 = T1 + 1024;
+    constexpr int N = 2048, M = 1024, hop = OW_HOP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = (a.n_frames + NW - 1) / NW, total = a.n_signals * groups;
+    const int len = hop * (a.n_frames - 1);
+    wave_fft_tables(T1, T2);
+    float cb, sb, sc, ss, sc2, ss2;
+    sincospif(2.0f * (float)lane / 1024.0f, &sb, &cb);
+    const float inv = 1.0f / (float)M;
+    sincospif((float)(1 + (int)(threadIdx.x >> 1)) / (float)M, &ss, &sc);
+    sincospif((float)(257 + (int)(threadIdx.x >> 1)) / (float)M, &ss2, &sc2);
+    const bool vec4 = (a.n_frames & 3) == 0 && ((a.a_bs | a.b_bs) & 3) == 0 && ((((uintptr_t)a.a) | ((uintptr_t)a.b)) & 15) == 0;
+    const WssCtx wc = wss_ctx(4 * (int)threadIdx.x, N, hop);
+    const int half = threadIdx.x & 1;
+    __syncthreads();
+    for (GroupWalk gw = group_walk(total); gw.g < gw.end; gw.g += gw.step) {
+        const int sig = gw.g / groups, grp = gw.g - sig * groups, t0 = grp * NW;
+        const int nfr = min(NW, a.n_frames - t0);
+        const int n4 = nfr - 4 * half;
+        if (n4 > 0) {                                         // Z[k] = E[k] + i O[k] (see istft_frames4_kernel)
+            const float* pa = a.a + (long)sig * a.a_bs + t0 + 4 * half;
+            const float* pb = a.b + (long)sig * a.b_bs + t0 + 4 * half;
+            const bool vec = vec4 && n4 >= 4;
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {
+                const int k = 1 + (int)(threadIdx.x >> 1) + 256 * i;
+                const float sn = i ? ss2 : ss, cs = i ? sc2 : sc;
+                float2 Xk[SF], Xm[SF];
+                istft_row(a, pa, pb, k, n4, vec, Xk);
+                istft_row(a, pa, pb, k == M - k ? M : M - k, n4, vec, Xm);   // (the self-paired threads read the Nyquist row here)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const float2 Xo = k == M - k ? Xk[f] : Xm[f];
+                    const float2 E = make_float2(0.5f * (Xk[f].x + Xo.x), 0.5f * (Xk[f].y - Xo.y));
+                    const float2 D = make_float2(0.5f * (Xk[f].x - Xo.x), 0.5f * (Xk[f].y + Xo.y));
+                    const float2 O = cmul(D, make_float2(cs, sn));
+                    regs[4 * half + f][k] = make_float2(E.x - O.y, E.y + O.x);
+                    if (k != M - k) regs[4 * half + f][M - k] = make_float2(E.x + O.y, O.x - E.y);
+                    else regs[4 * half + f][0] = make_float2(0.5f * Xm[f].x, -0.5f * Xm[f].x);      // Z[0]: X[0] = 0, X[M] real
+                }
+            }
+        }
+        lds_barrier();
+        if (wave < nfr) {                                     // this wave's frame: inverse transform, window, back to its region as 2048 reals
+            float2 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = regs[wave][lane + 64 * r];
+            wave_order();
+            wave_fft1024<-1>(v, regs[wave], T1, T2, lane);
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            const int k1 = lo & 15, kh = lo >> 4;
+            float cbo = cb, sbo = sb;
+            asm volatile("" : "+v"(cbo), "+v"(sbo));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float cq = __fmaf_rn(cbo, W8C[q], -(sbo * W8S[q])), sq = __fmaf_rn(sbo, W8C[q], cbo * W8S[q]);     // + q pi / 8
+#pragma unroll
+                for (int k3 = 0; k3 < 4; ++k3) {
+                    const float c = k3 == 0 ? cq : k3 == 1 ? -sq : k3 == 2 ? -cq : sq;                              // + k3 pi / 2
+                    const float sn = k3 == 0 ? sq : k3 == 1 ? cq : k3 == 2 ? -sq : -cq;
+                    float w0, w1;
+                    hann_pair(c, sn, w0, w1);
+                    const float2 z = v[4 * q + k3];
+                    regs[wave][k1 + 16 * (4 * q + kh) + 256 * k3] = make_float2(z.x * (inv * w0), z.y * (inv * w1));
+                }
+            }
+        }
+        lds_barrier();
+        // overlap-add over the group's frames: position pr (relative to t0 hop) gets frame f's sample pr - f hop
+        const bool first = grp == 0, last = grp == groups - 1;
+        float mx = 0.f;
+        float* out = a.audio + (long)sig * len;
+        float* tl = tails + ((long)sig * groups + grp) * (OW_HB * hop);
+        for (int pr = 4 * (int)threadIdx.x; pr < (NW + OW_HB) * hop; pr += 4 * WT) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int f = 0; f < NW; ++f) {
+                const int n = pr - f * hop;
+                if (f < nfr && n >= 0 && n < N) {
+                    const float4 q = *(const float4*)((const float*)regs[f] + n);
+                    acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w;
+                }
+            }
+            const int blk = pr / hop, ip = t0 * hop + pr, i0 = ip - (N >> 1);
+            if (blk >= NW && !last) { *(float4*)(tl + (pr - NW * hop)) = acc; continue; }        // tail: the next group's seam adds it
+            if (i0 < 0 || i0 >= len) continue;                                                  // trimmed away
+            if (blk < OW_HB && !first) { *(float4*)(out + i0) = acc; continue; }                 // head: partial sum, finalised at the seam
+            mx = fmaxf(mx, ola_finalize(acc, ip, N, hop, a.n_frames, wc));
+            *(float4*)(out + i0) = acc;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        if (lane == 0) red[wave] = mx;
+        lds_barrier();                                        // (also: the regions are the next group's work space)
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < NW; ++i) mx = fmaxf(mx, red[i]);
+            partial[(long)sig * 2 * groups + grp] = mx;
+            if (first) partial[(long)sig * 2 * groups + groups] = 0.f;       // group 0 has no seam in front of it
+        }
+    }
+}
+
+// the seams: head blocks of every group but the first = their own partial sums (in the audio buffer) + the previous group's tail
+__global__ __launch_bounds__(256) void istft_seam_kernel(const pg_istft_args a, const float* tails, float* partial) {
+    __shared__ float red[4];
+    constexpr int N = 2048, hop = OW_HOP;
+    const int groups = (a.n_frames + NW - 1) / NW;
+    const int sig = blockIdx.y, grp = 1 + blockIdx.x;                        // grid (groups - 1, signals)
+    const int len = hop * (a.n_frames - 1), t0 = grp * NW;
+    float* out = a.audio + (long)sig * len;
+    const float* tl = tails + ((long)sig * groups + grp - 1) * (OW_HB * hop);
+    const WssCtx wc = wss_ctx(4 * (int)threadIdx.x, N, hop);                 // (256 threads: 1024 positions per pass, hop divides it)
+    float mx = 0.f;
+    for (int pr = 4 * (int)threadIdx.x; pr < OW_HB * hop; pr += 4 * 256) {
+        const int ip = t0 * hop + pr, i0 = ip - (N >> 1);
+        if (i0 < 0 || i0 >= len) continue;
+        float4 acc = *(const float4*)(out + i0);
+        const float4 t = *(const float4*)(tl + pr);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        mx = fmaxf(mx, ola_finalize(acc, ip, N, hop, a.n_frames, wc));
+        *(float4*)(out + i0) = acc;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(long)sig * 2 * groups + groups + grp] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 
 __global__ void frame_index_kernel(int n_samples, int n_fft, int hop, int n_frames, int* idx) {
     const long total = (long)n_frames * n_fft;
@@ -886,7 +1173,7 @@ bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // the batched kernels hold 2 x SF frames of n_fft/2 complex points plus the twiddle table: 72 KB at n_fft = 2048
 constexpr int BATCHED_MAX_NFFT = 2048;
 size_t batched_lds(int n_fft) { return (size_t)(2 * SF * (n_fft / 2) + 3 * tw_len(n_fft / 2)) * sizeof(float2); }
-int wave_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (3 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }   // 43.5 KB of LDS: 3 per CU
+int wave_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (2 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }   // 78.3 KB of LDS: 2 per CU
 int batched_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (2 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }
 // the attribute belongs to (function, CURRENT device): set on every call (a host-side table write), so a process that drives
 // several devices is served too and nothing is cached between calls
@@ -895,6 +1182,10 @@ hipError_t batched_lds_ready() {
     hipError_t e = hipFuncSetAttribute((const void*)stft_frames_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_frames_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_frames4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_frames_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_ola_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS);
 
     return e;
 }
@@ -912,9 +1203,10 @@ extern "C" int pg_stft(const pg_stft_args* a, void* stream) {
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     if (a->n_fft <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
-        if (a->n_fft == 2048) {        // one wave per frame (wave_fft1024)
-            if (a->chunk_start) hipLaunchKernelGGL(stft_w_kernel<true>, dim3((unsigned)wave_grid(total)), dim3(256), 0, (hipStream_t)stream, *a);
-            else hipLaunchKernelGGL(stft_w_kernel<false>, dim3((unsigned)wave_grid(total)), dim3(256), 0, (hipStream_t)stream, *a);
+        if (a->n_fft == 2048) {        // one wave per frame (wave_fft1024), NW frames per workgroup
+            const int totw = a->n_signals * ((a->n_frames + NW - 1) / NW);
+            if (a->chunk_start) hipLaunchKernelGGL(stft_w_kernel<true>, dim3((unsigned)wave_grid(totw)), dim3(WT), WAVE_LDS, (hipStream_t)stream, *a);
+            else hipLaunchKernelGGL(stft_w_kernel<false>, dim3((unsigned)wave_grid(totw)), dim3(WT), WAVE_LDS, (hipStream_t)stream, *a);
         }
         else if (a->chunk_start) hipLaunchKernelGGL(stft_frames_kernel<true>, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
         else hipLaunchKernelGGL(stft_frames_kernel<false>, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
@@ -936,8 +1228,9 @@ extern "C" int pg_stft_frame_index(int32_t n_samples, int32_t n_fft, int32_t hop
 }
 
 static int ola_blocks(const pg_istft_args* a) { return (a->hop * (a->n_frames - 1) + 256 * OLA_SPT - 1) / (256 * OLA_SPT); }
-static int64_t ola_partial_bytes(const pg_istft_args* a) {
-    const int64_t b = (int64_t)a->n_signals * ola_blocks(a) * (int64_t)sizeof(float);
+static int64_t ola_partial_bytes(const pg_istft_args* a) {      // per-workgroup peaks: the overlap-add kernel's blocks, or (n_fft = 2048 at
+    const int64_t per = ola_blocks(a) > 2 * ((a->n_frames + 7) / 8) ? ola_blocks(a) : 2 * ((a->n_frames + 7) / 8);   // hop 512) 2 x groups
+    const int64_t b = (int64_t)a->n_signals * per * (int64_t)sizeof(float);
     return (b + 255) / 256 * 256;
 }
 
@@ -958,18 +1251,29 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
     float* frames = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));
     hipError_t e;
     if ((e = batched_lds_ready()) != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
+    const int len = a->hop * (a->n_frames - 1);
+    int bx = (len / 4 + 255) / 256; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
+    // n_fft = 2048 at hop 512 (the reference's defaults, preproc_mdb.py:202-204) on 16 B-aligned audio: overlap-add inside the transform
+    // kernel, seams fixed by a second one; the workspace holds [256 B][2 x groups peaks per signal][tails]
+    if (N == 2048 && a->hop == OW_HOP && !a->single_frame && (((uintptr_t)a->audio) & 15) == 0) {
+        const int groups = (a->n_frames + NW - 1) / NW;
+        float* tails = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));     // (2 x groups <= the overlap-add's block count: fits)
+        hipLaunchKernelGGL(istft_ola_w_kernel, dim3((unsigned)wave_grid(a->n_signals * groups)), dim3(WT), WAVE_LDS, st, *a, tails, partial);
+        if (groups > 1) hipLaunchKernelGGL(istft_seam_kernel, dim3(groups - 1, a->n_signals), dim3(256), 0, st, *a, (const float*)tails, partial);
+        if (a->normalize) hipLaunchKernelGGL(istft_peak_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const float*)partial, 2 * groups);
+        e = hipGetLastError();
+        return e == hipSuccess ? PG_OK : pg_fail((int)e, hipGetErrorString(e));
+    }
     if (N <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
-        if (N == 2048) hipLaunchKernelGGL(istft_frames_w_kernel, dim3((unsigned)wave_grid(total)), dim3(256), 0, st, *a, frames);
+        if (N == 2048) hipLaunchKernelGGL(istft_frames_w_kernel, dim3((unsigned)wave_grid(a->n_signals * ((a->n_frames + NW - 1) / NW))), dim3(WT), WAVE_LDS, st, *a, frames);
         else hipLaunchKernelGGL(istft_frames4_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(N), st, *a, frames);
     } else {
         const size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
         hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)(a->n_signals * a->n_frames)), dim3(FFT_THREADS), lds, st, *a, frames);
     }
-    const int len = a->hop * (a->n_frames - 1);
     const int nblk = ola_blocks(a);
     hipLaunchKernelGGL(istft_ola4_kernel, dim3(nblk, a->n_signals), dim3(256), 0, st, *a, (const float*)frames, partial);
-    int bx = (len / 4 + 255) / 256; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
     // the peak over the overlap-add's per-workgroup peaks and the division by it are ONE launch (round 3: two)
     if (a->normalize) hipLaunchKernelGGL(istft_peak_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const float*)partial, nblk);
     e = hipGetLastError();
