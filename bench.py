@@ -658,6 +658,54 @@ def other_configs(torch, dist, model, C, L, B):
                                     note="the reference's own defaults, train.py:14-15: batch 16, 1024 bins x 128 frames"))
     leg("fwd", fwd)
     leg("e2e", e2e)
+    leg("demo_clip", lambda: measure_demo_clip(torch, model, C))
+    return out
+
+
+def measure_demo_clip(torch, model, C):
+    """demo.py's timed region (demo.py:33-45: one clip of 1024 bins x 128 frames -> forward -> (exp(m) - 1) e^{j phi} -> ISTFT -> host),
+    per MFMA operand mode.  At batch 1 a forward is one pass over the 2.45 GB of weights (N = 65 ... 14 columns per layer): the conv
+    launches are priced against HBM (weight bytes / time / 8 TB/s) next to their MFMA fraction."""
+    from phasegen import audio, ops
+    L = 128
+    d = synthetic_batch(torch, 1, C, L, 5)
+    fl = conv_flops(C, L, 1)
+    wbytes = {"fp32": 4.0, "bf16": 2.0}
+    out = {"workload": f"demo.py:33-45: 1 clip x {C} bins x {L} frames, forward + ISTFT + device->host", "weights": sum(
+        int(v.numel()) for k, v in ((k, model.engine.arena.p(k)) for k in model.engine.arena.shapes) if v.dim() == 3)}
+    old = model.engine.precision
+    try:
+        for mode in ("fp32", "bf16"):
+            model.engine.precision = ops.precision_code(mode)
+
+            def clip():
+                with torch.no_grad():
+                    pred = model.forward(d[:, 0])
+                    return audio.synthesize(d[:, 0], pred[:, :C], 512).cpu()
+            for _ in range(3):
+                clip()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                clip()
+            ms = (time.perf_counter() - t0) / 10 * 1e3
+            timer = ops.KernelTimer()
+            ops.set_timer(timer)
+            for _ in range(3):
+                clip()
+            torch.cuda.synchronize()
+            ops.set_timer(None)
+            conv = {k: v[1] for k, v in timer.summary().items() if not k.startswith("hbm:")}
+            conv_ms = sum(conv.values())
+            nb = out["weights"] * wbytes[mode]
+            peak = PEAK_FP32_MFMA_TFLOPS if mode == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            out[mode] = {"ms_per_clip": round(ms, 4), "conv_launches_ms": round(conv_ms, 4), "weight_bytes": nb,
+                         "weight_TBps": round(nb / conv_ms / 1e9, 3), "frac_of_hbm_peak": round(nb / conv_ms / 1e9 / PEAK_HBM_TBPS, 4),
+                         "conv_tflops": round(sum(fl.values()) / conv_ms / 1e9, 1), "frac_of_mfma_peak": round(sum(fl.values()) / conv_ms / 1e9 / peak, 4),
+                         "by_layer_ms": {k: round(v, 4) for k, v in sorted(conv.items())},
+                         "plans": {k: timer.plans.get(k, "?").split("|")[0] for k in sorted(conv)}}
+    finally:
+        model.engine.precision = old
     return out
 
 

@@ -117,8 +117,8 @@ int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, int32_t bufle
 typedef struct pg_convh_args {
     int32_t B, Cin, Cout, Lin, Lout, k, stride, pad;
     int32_t transposed;              /* 0: nn.Conv1d forward (model.py:77-78), 1: nn.ConvTranspose1d forward (model.py:88-102) */
-    int32_t schedule;                /* as pg_conv_args.schedule; plus the tile family (tests, measurements): bits 5-6 = 1: 128 x 256 on 4
-                                      * waves, 2: 128 x 512, 3: 256 x 256 on 8 waves; bit 12: 256 x 256 on 4 waves, one per SIMD; none: automatic */
+    int32_t schedule;                /* work-split bits of pg_conv_args.schedule (0-1, 4, 8-11).  One tile family since 0.4 (256 x 256 on 4
+                                      * waves, one per SIMD); bits 5-6, which selected the removed ones, return PG_ERR_UNSUPPORTED */
     const uint16_t* x; int64_t x_bs; /* bf16 (B, Cin, x_pitch), batch stride in elements */
     int32_t x_pitch; int32_t _pad0;
     const uint16_t* w;               /* pg_shadow_weights output for this layer */

@@ -107,7 +107,7 @@ def test_per_call_knobs_are_validated_and_steer_the_launch_plan():
     assert "grid=1536|tiles=1056" in dd2 and "split=1" in dd2 and "whole=1024" in dd2
     assert ops.conv_describe(_u0_args(lib, precision=1), _lib.OP_CONVT1D_FWD).startswith("conv_raw_kernel<32, 2, true, 1, 2>|")
     assert ops.conv_describe(_u0_args(lib, precision=2), _lib.OP_CONVT1D_WGRAD).startswith("conv_g_raw_kernel<32, 2, 2>|")
-    assert ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_NO_RAW), _lib.OP_CONVT1D_DGRAD).startswith("conv_f_kernel<32, 2, 0>|")
+    assert ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_NO_RAW), _lib.OP_CONVT1D_DGRAD).startswith("conv_f_kernel<0, 0, 0>|")
     one = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_TILE_PER_WG), _lib.OP_CONVT1D_FWD)
     assert "split=0" in one and "grid=512|tiles=512" in one
     g4 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_FORCE_STREAMK), _lib.OP_CONVT1D_DGRAD)

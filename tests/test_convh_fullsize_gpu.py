@@ -1,4 +1,4 @@
-"""GPU: the bf16-RESIDENT forward kernels (csrc/conv_h.hip, BASELINE configs[4]) pinned at the REAL geometry -- batch 64, C = 1024,
+"""GPU: the bf16-RESIDENT forward kernels (csrc/conv_h3.hip, BASELINE configs[4]) pinned at the REAL geometry -- batch 64, C = 1024,
 256 frames, every one of the eight layers (the small-size oracle comparisons live in tests/test_convh_gpu.py):
 
   1. each layer alone, under the three work-split schedules: a hundred output values recomputed on the host in float64 from
@@ -52,7 +52,7 @@ def sample_points(rng, n, Cout, Lout):
     return pts
 
 
-@pytest.mark.parametrize("sched", [0, 1, 2, 32, 64, 96, 4096], ids=["auto", "tile-per-wg", "stream-k", "128x256", "128x512", "256x256", "256x256w4"])
+@pytest.mark.parametrize("sched", [0, 1, 2], ids=["auto", "tile-per-wg", "stream-k"])
 @pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
 def test_conv_h_layer_at_full_size(layer, sched):
     from phasegen import ops

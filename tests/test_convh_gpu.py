@@ -1,4 +1,4 @@
-"""GPU: the bf16-RESIDENT forward convolutions (csrc/conv_h.hip, BASELINE configs[4]) against a float64 convolution of the
+"""GPU: the bf16-RESIDENT forward convolutions (csrc/conv_h3.hip, BASELINE configs[4]) against a float64 convolution of the
 SAME bf16 operands (products of bf16 values are exact in fp32, so only the accumulation order differs: 2e-5 of max-abs), at
 every (k, stride) geometry of the U-Net, at ragged sizes (partial tiles in M and N, several samples per tile, odd frame counts
 whose last bf16 pair is half padding) and under both work decompositions; plus the helper kernels (weight shadow, row cast,
@@ -34,14 +34,13 @@ GEOMS = [
 ]
 
 
-# schedule word: bits 0-1 work split (0 auto, 1 one tile per workgroup, 2 stream-K), bits 5-6 tile family (32: 128 x 256 on 4 waves,
-# 64: 128 x 512 and 96: 256 x 256 on 8 waves; 0: automatic), bit 12 (4096: 256 x 256 on 4 waves, one per SIMD -- conv_h3.hip)
-SCHEDS = [0, 1, 2, 32 | 1, 32 | 2, 64 | 1, 64 | 2, 96 | 1, 96 | 2, 4096 | 1, 4096 | 2]
+# schedule word: bits 0-1 work split (0 auto, 1 one tile per workgroup, 2 stream-K).  One tile family since ABI 0.4 (256 x 256 on 4
+# waves, one per SIMD: conv_h3.hip); bits 5-6, which selected the removed families, are refused (test below)
+SCHEDS = [0, 1, 2]
 
 
 @pytest.mark.parametrize("geom", GEOMS)
-@pytest.mark.parametrize("sched", SCHEDS, ids=["auto", "tile-per-wg", "stream-k", "128x256/tile", "128x256/stream-k", "128x512/tile",
-                                               "128x512/stream-k", "256x256/tile", "256x256/stream-k", "256x256w4/tile", "256x256w4/stream-k"])
+@pytest.mark.parametrize("sched", SCHEDS, ids=["auto", "tile-per-wg", "stream-k"])
 def test_conv_fwd_h_vs_float64_of_the_bf16_operands(geom, sched):
     from phasegen import ops
     tr, Cin, Cout, k, s, p, Lin, B = geom
@@ -89,6 +88,24 @@ def test_weight_shadow_layouts():
                     assert sh5[o * 2 + phi, q * 4 + jj] == (w5.to(torch.bfloat16)[q, o, j] if j < 5 else 0)
     w2 = rnd(6, 5, 3, 8)                                     # Conv1d (Cout=5, Cin=3, k=8): a cast
     assert torch.equal(ops.shadow_weights(w2.cuda(), False, 1).cpu(), w2.to(torch.bfloat16).reshape(-1))
+
+
+def test_removed_tile_families_are_refused():
+    """ABI 0.4 removed the 128 x 256 / 128 x 512 / eight-wave 256 x 256 tiles (no automatic choice reached them): schedule bits 5-6 are
+    an error now, bit 12 (the surviving family) is accepted and changes nothing."""
+    from phasegen import ops
+    B, Cin, Cout, k, s, p, Lin = 1, 8, 16, 32, 2, 16, 24
+    w = rnd(3, Cout, Cin, k)
+    wh = ops.shadow_weights(w.cuda(), False, s)
+    xh = ops.h_alloc(B, Cin, Lin, "cuda")
+    y = torch.empty(B, Cout, ops.conv_out_len(Lin, k, s, p), device="cuda")
+    for bad in (32, 64, 96, 32 | 1):
+        with pytest.raises(RuntimeError, match="removed"):
+            ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, y=y, schedule=bad)
+    ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, y=y, schedule=4096)
+    y0 = y.clone()
+    ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, y=y, schedule=0)
+    assert torch.equal(y, y0)
 
 
 def test_unsupported_geometries_are_refused():
@@ -218,9 +235,8 @@ def test_conv_fwd_h_random_geometries(geom):
     if ops.conv_fwd_h_supported(B, tuple(w.shape), Lin, s, p, tr):
         ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y)
         assert relerr(y, want) < 2e-5
-        # ... under every tile family with the stream-K split forced (partial tiles through the workspace + the fixup kernels; the
-        # 8-wave families run the three-stage ring with counted waits) and one tile per workgroup
-        for sched in (32 | 2, 64 | 2, 96 | 2, 64 | 1, 96 | 1, 4096 | 1, 4096 | 2):
+        # ... with the stream-K split forced (partial tiles through the workspace + the fixup kernel) and one tile per workgroup
+        for sched in (2, 1):
             y.fill_(float("nan"))
             ops.conv_fwd_h(xh, Lin, wh, tuple(w.shape), s, p, transposed=tr, y=y, schedule=sched)
             assert relerr(y, want) < 2e-5, sched
@@ -246,7 +262,7 @@ def test_conv_h3_is_race_free_by_repetition(geom):
     xh = ops.h_alloc(B, Cin, Lin, "cuda")
     ops.cast_rows_bf16(x.cuda(), xh)
     wh = ops.shadow_weights(w.cuda(), tr, s)
-    for sched in (4096 | 2, 4096 | 1):
+    for sched in (2, 1):
         first = None
         for it in range(int(os.environ.get("PG_RACE_REPS", "40"))):       # (a one-off soak: PG_RACE_REPS=400)
             y = torch.empty(tuple(want.shape), device="cuda")

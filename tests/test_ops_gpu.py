@@ -47,7 +47,7 @@ GEOMS = [
     # column tile, several samples per tile): every (k, s) pair and form they cover
     (False, 32, 250, 8, 2, 1, 130, 5), (True, 48, 120, 8, 2, 1, 70, 4), (True, 64, 128, 32, 2, 16, 65, 3), (False, 16, 250, 32, 2, 16, 200, 3),
     (True, 32, 250, 8, 1, 2, 100, 3), (False, 32, 500, 4, 2, 1, 160, 4), (False, 48, 230, 8, 1, 2, 90, 4),
-    # ... and for the one-wave-per-SIMD wgrad (conv_g3.hip): ~250 rows of P; samples of 16 cf + 1 / + 2 frames at a batch of 16 / 32
+    # ... and sized for 256-row tiles (the removed one-wave-per-SIMD wgrad, conv_g3.hip, was tested on them): ~250 rows of P; samples of 16 cf + 1 / + 2 frames at a batch of 16 / 32
     # (the rem last frames of 16 samples form "leftover" slabs), and frame counts whose padding to whole slabs costs <= 7 % (0, 3.2, 6.7 %)
     (False, 16, 250, 32, 2, 16, 64, 16), (False, 24, 250, 32, 2, 16, 66, 32), (True, 250, 16, 32, 2, 16, 33, 16),
     (False, 40, 250, 8, 1, 2, 34, 3), (False, 40, 250, 8, 2, 1, 125, 3), (False, 70, 250, 4, 2, 1, 62, 5), (True, 250, 24, 8, 2, 1, 31, 4),
@@ -387,7 +387,7 @@ def test_conv_random_geometries_vs_torch(geom):
 
 
 def _random_geoms_one_wave(n, seed):
-    """Seeded sweep sized for the one-wave-per-SIMD fp32 kernels (conv_raw3.hip, and conv_g3.hip under schedule bit 14): GEMM rows
+    """Seeded sweep sized for the one-wave-per-SIMD fp32 kernels (conv_raw3.hip; schedule bit 14 forces them wherever they cover the problem): GEMM rows
     just under a multiple of 256 on the side that matters, channel counts that give whole 16-deep slabs, frame counts from less than a
     column tile to several samples per tile, every (k, stride) pair they cover, paddings up to k - 1."""
     rs = np.random.RandomState(seed)

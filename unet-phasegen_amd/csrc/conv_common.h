@@ -30,7 +30,7 @@ struct IgemmParams {
     float* ws;                       // stream-K partial-tile workspace: [grid][2][64][256] floats (or NULL)
     int nslab;                       // K slabs per tile
     int whole;                       // workgroups that own one whole tile each (hybrid split; 0 = even split)
-    // bf16-resident forward kernels (conv_h.hip): x and w are bf16; rows of x are x_pitch elements apart (even, zero tail);
+    // bf16-resident forward kernels (conv_h3.hip): x and w are bf16; rows of x are x_pitch elements apart (even, zero tail);
     // optional bf16 outputs (B, M, yh_pitch) stored already activated.  All NULL / 0 for the fp32-tensor kernels.
     int x_pitch;
     unsigned short* yh; long yh_bs; int yh_pitch; float yh_slope;
@@ -521,10 +521,6 @@ hipError_t launch_im2col(int kind, const IgemmParams& p, int grid, hipStream_t s
 hipError_t launch_raw_ft(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw.hip (F / T, tile 128 x 256)
 hipError_t launch_raw_ft_tall(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec);   // conv_raw_tall.hip (256 x 128)
 hipError_t launch_raw_g(const IgemmParams& p, int grid, hipStream_t st, int prec);              // conv_raw_wgrad.hip
-hipError_t launch_h(int kind, const IgemmParams& p, int grid, hipStream_t st);                  // conv_h.hip (bf16-resident forward, 128 x 256, 4 waves)
-// conv_h2.hip: the same on 8 waves, one workgroup per CU; wm = 1: tile 128 x 512, wm = 2: tile 256 x 256
-hipError_t launch_h2(int kind, int wm, const IgemmParams& p, int grid, hipStream_t st);
-hipError_t launch_h2_fixup(int kind, int wm, const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
 // conv_h3.hip: 4 waves at ONE per SIMD, wave tile 256 x 64, tile 256 x 256
 hipError_t launch_h3(int kind, const IgemmParams& p, int grid, hipStream_t st);
 hipError_t launch_h3_fixup(int kind, const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
@@ -532,9 +528,5 @@ hipError_t launch_h3_fixup(int kind, const IgemmParams& p, int grid, unsigned bl
 bool raw3_covers(int kind, const IgemmParams& p);               // (k, s) pair and whole-slab K; the window-length bound is raw_supported's
 hipError_t launch_raw3(int kind, const IgemmParams& p, int grid, hipStream_t st);
 hipError_t launch_raw3_fixup(int kind, const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
-// conv_g3.hip: fp32 wgrad on 4 waves at ONE per SIMD, tile 256 x 256; mode 1 = padded per-sample slabs, 2 = leftover slabs
-hipError_t launch_g3(const IgemmParams& p, int mode, int grid, hipStream_t st);
-hipError_t launch_g3_fixup(const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
-bool h_supported_tn(int kind, const IgemmParams& p, int tn);      // geometry covered by a bf16-resident kernel whose tile is tn columns wide
-inline bool h_supported(int kind, const IgemmParams& p) { return h_supported_tn(kind, p, 256); }
+bool h_supported(int kind, const IgemmParams& p);               // geometry covered by the bf16-resident kernels (conv_h3.hip)
 }  // namespace pgconv

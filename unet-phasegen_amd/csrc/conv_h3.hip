@@ -378,6 +378,40 @@ hipError_t launch3(const IgemmParams& p, int grid, hipStream_t st) {
 
 }  // namespace
 
+// do the windows of every possible 256-column tile fit the reserved dwords, and is the rows' zero tail long enough?
+// (host-side mirror of the kernel's geometry: pg_conv_fwd_h_supported)
+bool pgconv::h_supported(int kind, const IgemmParams& p) {
+    constexpr int tn = 256;
+    const bool t = kind == KIND_T;
+    if (kind == KIND_G) return false;
+    if (t) { if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 5 && p.s == 2))) return false; }
+    else if (!((p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2))) return false;
+    const int kwp = t ? pg_shadow_taps(p.k, p.s) : p.k, tj = kwp < 32 ? kwp : 32, nq = 32 / tj, sc = t ? 1 : p.s;
+    if (p.Q % nq || (p.x_pitch & 1) || (p.x_bs & 1) || p.x_pitch <= p.Lx) return false;
+    const int lcol = t ? p.U : p.Ly, rsd = h3_rsd(sc);
+    const int pos_mid = t ? p.u_off - (tj - 1) : -p.p, shm = pos_mid & 1;
+    const int ndm = h3_round4((sc * (lcol - 1) + tj + shm + 1) >> 1);
+    // elements of a row's neighbourhood a window piece can touch: [pos_mid - shm, pos_mid - shm + 2 ndm) for a sample's first
+    // column at frame 0; a first segment that starts at column t0 ends no later (its window is the same one cut at t0, rounded
+    // up to a piece: + 6 elements at most)
+    const int left = pos_mid - shm < 0 ? -(pos_mid - shm) : 0;
+    const int right = pos_mid - shm + 2 * ndm + 6 - p.Lx;
+    const int tail = p.x_pitch - p.Lx;
+    if (left > H_HEAD || tail < left || tail < right) return false;
+    // the kernel lays the samples' windows out back to back (segment 0, full middle segments, last partial one): the worst
+    // first-column position t0 must fit the reserved dwords
+    int need = 0;
+    for (int t0 = 0; t0 < lcol; ++t0) {
+        const int nc0 = lcol - t0 < tn ? lcol - t0 : tn, rem = tn - nc0;
+        const int sh0 = (pos_mid + sc * t0) & 1;
+        int nmid = rem / lcol, nlast = rem - nmid * lcol;                        // full middle samples, columns of the last one
+        if (1 + nmid + (nlast ? 1 : 0) > p.B) { nlast = 0; if (1 + nmid > p.B) nmid = p.B - 1; }   // only B samples exist
+        const int n = h3_round4((sc * (nc0 - 1) + tj + sh0 + 1) >> 1) + nmid * ndm + (nlast ? (sc * (nlast - 1) + tj + shm + 2) >> 1 : 0);
+        if (n > need) need = n;
+    }
+    return need <= rsd;
+}
+
 hipError_t pgconv::launch_h3(int kind, const IgemmParams& p, int grid, hipStream_t st) {
     if (kind == KIND_F) {
         if (p.k == 32) return launch3<32, 2, false>(p, grid, st);

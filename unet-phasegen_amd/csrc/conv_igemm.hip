@@ -95,8 +95,6 @@ struct Knobs {
     int no_ps;        // wgrad: 1 = never the per-sample-slab kernel (A/B, tests)
     int no_raw3;      // 1 = never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip; schedule bit 13: A/B, tests of the older kernels)
     int all_raw3;     // 1 = the one-wave-per-SIMD kernels wherever they cover the problem (bit 14), also where auto prefers the older ones
-    int hvar;         // pg_conv_fwd_h only: tile family, 0 automatic, 1 = 128 x 256 (4 waves), 2 = 128 x 512, 3 = 256 x 256 (8 waves),
-                      // 4 = 256 x 256 on 4 waves at one per SIMD (conv_h3.hip; schedule bit 12)
     char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
 };
 int decode_knobs(const pg_conv_args* a, Knobs& k) {
@@ -107,8 +105,9 @@ int decode_knobs(const pg_conv_args* a, Knobs& k) {
     k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
     k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
     k.contended = (sc >> 4) & 1;
-    k.hvar = (sc >> 5) & 3;
-    if (sc & 0x1000) { if (k.hvar) return pg_fail(PG_ERR_SHAPE, "conv: schedule bit 12 excludes bits 5-6"); k.hvar = 4; }
+    // bits 5-6 selected the two-waves-per-SIMD / eight-wave tile families of pg_conv_fwd_h until 0.3 (conv_h.hip, conv_h2.hip): no
+    // automatic choice reached them once conv_h3 was the default for every layer, and they are gone (0.4); bit 12 (conv_h3) is a no-op
+    if ((sc >> 5) & 3) return pg_fail(PG_ERR_UNSUPPORTED, "conv: schedule bits 5-6 (tile families removed in 0.4)");
     k.no_ps = (sc >> 7) & 1;
     k.no_raw3 = (sc >> 13) & 1;
     k.all_raw3 = (sc >> 14) & 1;
@@ -195,21 +194,6 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     const bool tall = kind != KIND_G && kn.no_raw == 0 && kn.no_tall == 0 && (cols_tall * 100 <= cols_wide * 97 || !raw) &&
                       raw_supported(kind, p, kn, RBN / 2);
     if (tall) raw = true;
-    // fp32 wgrad on one wave per SIMD (conv_g3.hip: 256 x 256 tiles, slabs that never straddle samples): mode 1 pads every sample to
-    // whole 16-frame slabs (as the per-sample-slab kernel below: where that costs <= 7 % of MFMA work), mode 2 (samples of 16 cf + rem
-    // frames with rem <= 2, batch a multiple of 16: the k = 32 layers at 129 frames) gathers the rem last frames of 16 samples
-    // element-wise instead -- no padded work.  OPT-IN (schedule bit 14) only: measured 0.73-0.78 of the pipe against 0.82-0.86 for the
-    // two-waves-per-SIMD kernels -- its fragment fix-ups (activations, padding, range checks) and the wave-uniform branches around
-    // them sit in the MFMA gaps but still cost issue slots, and the fused Adam epilogue is exposed at one workgroup per CU
-    // (DESIGN.md section 4.1b).
-    int g3 = 0;
-    if (raw && kind == KIND_G && kn.prec == 0 && kn.all_raw3 && !kn.no_ps && (p.k == 32 || p.k == 8 || p.k == 4) &&
-        p.act_x == PG_ACT_NONE && p.act_p == PG_ACT_NONE &&
-        (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103) {
-        const long cps = (p.LP + 15) / 16, rem = p.LP % 16;
-        if (rem && rem <= 2 && p.B % 16 == 0 && (cps * 16 - p.LP) * 100 > 2L * p.LP) { g3 = 2; Ktot = (long)p.B * p.LP; }
-        else if ((cps * 16 - p.LP) * 100 <= 7L * p.LP) { g3 = 1; Ktot = (long)p.B * cps * 16; }
-    }
     // fp32 F / T problems the one-wave-per-SIMD kernels cover (conv_raw3.hip: 256 x 256 tile) take them, unless 256-row tiles
     // would compute over 3 % more rows than 128-row ones
     // Over the tall tile too where 256-wide tiles compute at most 8 % more columns (D2 forward / U2 dgrad / D3 forward at batch 64:
@@ -217,12 +201,12 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     const bool r3_over_tall = tall && raw_supported(kind, p, kn) && (kn.all_raw3 || cols_wide * 100 <= cols_tall * 108);
     const bool r3 = raw && (!tall || r3_over_tall) && kind != KIND_G && kn.prec == 0 && !kn.no_raw3 && pgconv::raw3_covers(kind, p) &&
                     (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103;
-    const int bm = (tall || r3 || g3) ? 2 * RBM : (raw ? RBM : BM);
+    const int bm = (tall || r3) ? 2 * RBM : (raw ? RBM : BM);
     int bn = (tall && !r3) ? RBN / 2 : (raw ? RBN : BN);
     const bool k5 = raw && p.k == 5 && p.s == 2;
     if (k5 && kind == KIND_G) bn = (RBN / 5) * 5;               // wgrad: a column tile is 51 whole channels x 5 taps = 255 columns (+ 1 idle)
     p.g_ps = 0;
-    if (raw && kind == KIND_G && p.k != 32 && !g3) {
+    if (raw && kind == KIND_G && p.k != 32) {
         // short samples: slabs of 16 frames of ONE sample (conv_g_ps_kernel) where padding every sample to whole slabs costs <= 7 %
         // of MFMA work (30 frames: 6.7 %, 61: 4.9 %, 126: 1.6 %, 256: none; 129 would cost 11.6 % and keeps the flat K axis)
         const long cps = (p.LP + 15) / 16;
@@ -235,30 +219,26 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     p.nslab = (int)((Ktot + BK - 1) / BK);
     const long tiles = (long)p.tilesM * p.tilesN;
     if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0 || cols + bn >= 0x7fffffffL) return pg_fail(PG_ERR_SHAPE, "conv: empty or oversize grid");   // the fixup launches 8 workgroups per tile
-    const int grid = (r3 || g3) ? pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG)
+    const int grid = r3 ? pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG)
                         : pick_grid(tiles, p.nslab, p, ws_bytes, kn.force_mode, kn.oversub, kn.contended);
     // ranges made of whole tiles (grid == tiles, or a grid that divides the tile count) leave nothing for the fixup
     const bool split = grid != tiles && !(tiles % grid == 0);
     if (kn.desc) {      // the kernel this call would launch, named as rocprofv3 names it (profiles/*_kernel_stats.csv)
-        const bool spec = (p.k == 32 && p.s == 2) || (p.k == 8 && p.s == 1) || (p.k == 8 && p.s == 2) || (p.k == 4 && p.s == 2) || (p.k == 5 && p.s == 2);
         char name[96];
-        if (g3) snprintf(name, sizeof name, "conv_g3_kernel<%d, %d, %s>", p.k, p.s, g3 == 1 ? "true" : "false");
-        else if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_%s_kernel<%d, %d, %d>", p.g_ps ? "ps" : "raw", p.k, p.s, kn.prec);
+        if (raw && kind == KIND_G) snprintf(name, sizeof name, "conv_g_%s_kernel<%d, %d, %d>", p.g_ps ? "ps" : "raw", p.k, p.s, kn.prec);
         else if (r3) snprintf(name, sizeof name, "conv_raw3_kernel<%d, %d, %s, %s>", p.k, p.s, kind == KIND_T ? "true" : "false", p.act_x == PG_ACT_NONE ? "false" : "true");
         else if (raw) snprintf(name, sizeof name, "conv_raw_kernel<%d, %d, %s, %d, %d>", p.k, p.s, kind == KIND_T ? "true" : "false", kn.prec, tall ? 1 : 2);
-        else snprintf(name, sizeof name, "conv_%c_kernel<%d, %d, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), spec ? p.k : 0, spec ? p.s : 0, kn.prec);
+        else snprintf(name, sizeof name, "conv_%c_kernel<0, 0, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), kn.prec);
         snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", name, grid, tiles, p.nslab, (int)split, p.whole);
         return PG_OK;
     }
     hipError_t e;
-    if (g3) e = pgconv::launch_g3(p, g3, grid, st);
-    else if (r3) e = pgconv::launch_raw3(kind, p, grid, st);
+    if (r3) e = pgconv::launch_raw3(kind, p, grid, st);
     else if (raw && kind == KIND_G) e = pgconv::launch_raw_g(p, grid, st, kn.prec);
     else if (tall) e = pgconv::launch_raw_ft_tall(kind, p, grid, st, kn.prec);
     else if (raw) e = pgconv::launch_raw_ft(kind, p, grid, st, kn.prec);
     else e = pgconv::launch_im2col(kind, p, grid, st, kn.prec);
-    if (e == hipSuccess && split && g3) e = pgconv::launch_g3_fixup(p, grid, (unsigned)((tiles - p.whole) * 16), st);
-    else if (e == hipSuccess && split && r3) e = pgconv::launch_raw3_fixup(kind, p, grid, (unsigned)((tiles - p.whole) * 16), st);
+    if (e == hipSuccess && split && r3) e = pgconv::launch_raw3_fixup(kind, p, grid, (unsigned)((tiles - p.whole) * 16), st);
     else if (e == hipSuccess && split) {
         if (tall) {
             if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
@@ -460,16 +440,6 @@ extern "C" int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, in
 }
 
 // ---- bf16-resident forward (conv_h.hip) ----------------------------------------------------------------------------------
-// automatic tile family of pg_conv_fwd_h (measured on MI355X at the U-Net's layer shapes, tools/convh_bench.py)
-static int h_auto_variant(bool tr, int kwp, int sc, long rows, long cols) {
-    (void)tr; (void)kwp; (void)sc; (void)rows; (void)cols;
-    // 256 x 256 on 4 waves, one per SIMD (conv_h3.hip), for every layer: inside the U-Net forward (bf16 outputs) it is level with
-    // or ahead of the best two-waves-per-SIMD family on all eight (tools/dbg/e2e_fam.py: forward 6.44 ms against 6.55 / 6.73 / 6.88
-    // with everything on 128 x 512 / 128 x 256 / 256 x 256 on 8 waves).  With an fp32 output alone (tools/convh_bench.py) the
-    // 128 x 512 tile keeps 3 % on D0; the other families stay selectable through the schedule word.
-    return 4;
-}
-
 static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, char* desc = nullptr, int desc_len = 0) {
     if (!a) return pg_fail(PG_ERR_NULL, "conv_fwd_h: null args");
     if (a->B <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->Lin <= 0 || a->Lout <= 0 || a->k <= 0 || a->stride <= 0 || a->pad < 0)
@@ -506,16 +476,13 @@ static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, cha
         p.U = (p.Ly - 1 + p.p) / p.s - p.u_off + 1;
         if (p.U <= 0) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: empty output");
     }
-    // Tile family (conv_h2.hip's header has the bytes-per-FLOP arithmetic): 1 = 128 x 256 on 4 waves, two workgroups per CU;
-    // 2 = 128 x 512 and 3 = 256 x 256 on 8 waves, one workgroup per CU; 4 = 256 x 256 on 4 waves, one workgroup per CU and one wave
-    // per SIMD (conv_h3.hip).  schedule bits 5-6 / bit 12 force one (tests, tools/convh_bench.py).
-    const bool ok1 = pgconv::h_supported_tn(kind, p, 256), ok2 = pgconv::h_supported_tn(kind, p, 512);
-    if (!ok1) return pg_fail(PG_ERR_UNSUPPORTED, "conv_fwd_h: geometry not covered by the bf16-resident kernels (use the fp32-tensor entry points)");
+    // ONE tile family since 0.4: 256 x 256 on 4 waves, one workgroup per CU and one wave per SIMD (conv_h3.hip).  Round 3 measured it
+    // level with or ahead of the 128 x 256 (conv_h.hip) and the eight-wave 128 x 512 / 256 x 256 tiles (conv_h2.hip) on all eight layers
+    // inside the forward (6.44 ms against 6.55 / 6.73 / 6.88), so those were never reached automatically and have been removed.
+    if (!pgconv::h_supported(kind, p)) return pg_fail(PG_ERR_UNSUPPORTED, "conv_fwd_h: geometry not covered by the bf16-resident kernels (use the fp32-tensor entry points)");
     if (query) return PG_OK;
     const long rows = tr ? (long)p.M * p.s : p.M, cols = (long)p.B * (tr ? p.U : p.Ly), Ktot = (long)p.Q * kwp;
-    int var = kn.hvar ? kn.hvar : h_auto_variant(tr, kwp, tr ? 1 : p.s, rows, cols);
-    if (var == 2 && !ok2) var = 3;
-    const int wm = var == 3 ? 2 : 1, tm = var >= 3 ? 2 * RBM : RBM, tn = var == 2 ? 2 * RBN : RBN;
+    const int tm = 2 * RBM, tn = RBN;
     p.tilesM = (int)((rows + tm - 1) / tm);
     p.tilesN = (int)((cols + tn - 1) / tn);
     p.tn_stride = tn;
@@ -523,26 +490,16 @@ static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, cha
     p.ws = (float*)a->workspace;
     const long tiles = (long)p.tilesM * p.tilesN;
     if (tiles <= 0 || tiles > 0x0fffffffL || p.nslab <= 0) return pg_fail(PG_ERR_SHAPE, "conv_fwd_h: empty or oversize grid");
-    const int grid = var == 1 ? pick_grid(tiles, p.nslab, p, a->workspace_bytes, kn.force_mode, kn.oversub, kn.contended)
-                              : pick_grid(tiles, p.nslab, p, a->workspace_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG);
+    const int grid = pick_grid(tiles, p.nslab, p, a->workspace_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG);
     const bool split = grid != tiles && !(tiles % grid == 0);
     if (desc) {
-        snprintf(desc, (size_t)desc_len, "conv_h%s_kernel<%d, %d, %s%s>|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", var == 1 ? "" : (var == 4 ? "3" : "2"),
-                 (tr && p.k == 5) ? 8 : p.k, p.s, tr ? "true" : "false", (var == 1 || var == 4) ? "" : (var == 2 ? ", 1" : ", 2"), grid, tiles, p.nslab, (int)split, p.whole);
+        snprintf(desc, (size_t)desc_len, "conv_h3_kernel<%d, %d, %s>|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d",
+                 (tr && p.k == 5) ? 8 : p.k, p.s, tr ? "true" : "false", grid, tiles, p.nslab, (int)split, p.whole);
         return PG_OK;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = var == 1 ? pgconv::launch_h(kind, p, grid, st) : var == 4 ? pgconv::launch_h3(kind, p, grid, st) : pgconv::launch_h2(kind, wm, p, grid, st);
-    if (e == hipSuccess && split) {
-        const unsigned blocks = (unsigned)((tiles - p.whole) * (var == 4 ? 16 : 8));
-        if (var == 4) e = pgconv::launch_h3_fixup(kind, p, grid, blocks, st);
-        else if (var != 1) e = pgconv::launch_h2_fixup(kind, wm, p, grid, blocks, st);
-        else {
-            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 4, 2, 4>), dim3(blocks), dim3(NT), 0, st, p, grid);
-            else hipLaunchKernelGGL((conv_fixup_kernel<1, 4, 2, 4>), dim3(blocks), dim3(NT), 0, st, p, grid);
-            e = hipGetLastError();
-        }
-    }
+    hipError_t e = pgconv::launch_h3(kind, p, grid, st);
+    if (e == hipSuccess && split) e = pgconv::launch_h3_fixup(kind, p, grid, (unsigned)((tiles - p.whole) * 16), st);
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     return PG_OK;
 }

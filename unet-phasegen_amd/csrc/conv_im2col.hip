@@ -191,12 +191,10 @@ hipError_t launch_kind(Kind kind, const IgemmParams& p, int grid, hipStream_t st
 
 }  // namespace
 
+// ONE instantiation per (form, operand mode): runtime (k, s).  Until 0.3 the U-Net's five (k, s) pairs had compile-time copies as well
+// (54 kernels, 3.5 MB of code object); since the raw-window kernels took every layer of the network, the im2col kernels only see
+// what those refuse -- generic (k, s), windows that do not fit a tile (many very short samples), k = 5 with an odd channel count,
+// wgrads of samples shorter than a slab -- where a division per gather does not matter.
 hipError_t pgconv::launch_im2col(int kind, const IgemmParams& p, int grid, hipStream_t st, int prec) {
-    const Kind k = (Kind)kind;
-    if (p.k == 32 && p.s == 2) return launch_kind<32, 2>(k, p, grid, st, prec);
-    if (p.k == 8 && p.s == 1) return launch_kind<8, 1>(k, p, grid, st, prec);
-    if (p.k == 8 && p.s == 2) return launch_kind<8, 2>(k, p, grid, st, prec);
-    if (p.k == 4 && p.s == 2) return launch_kind<4, 2>(k, p, grid, st, prec);
-    if (p.k == 5 && p.s == 2) return launch_kind<5, 2>(k, p, grid, st, prec);
-    return launch_kind<0, 0>(k, p, grid, st, prec);
+    return launch_kind<0, 0>((Kind)kind, p, grid, st, prec);
 }

@@ -19,8 +19,7 @@ SCHED_AUTO, SCHED_TILE_PER_WG, SCHED_FORCE_STREAMK, SCHED_NO_RAW, SCHED_NO_TALL,
 SCHED_NO_PS = 128      # wgrad: keep the flat-K raw kernel (no per-sample slabs)
 SCHED_NO_RAW3 = 0x2000  # fp32 F / T: never the one-wave-per-SIMD kernels (conv_raw3.hip)
 SCHED_ALL_RAW3 = 0x4000  # ... those kernels wherever they cover the problem (also the F form of k = 32, which auto leaves on the older ones)
-SCHED_H_128x256, SCHED_H_128x512, SCHED_H_256x256 = 32, 64, 96   # pg_convh_args.schedule bits 5-6: tile family of pg_conv_fwd_h (0 = automatic)
-SCHED_H_256x256_W4 = 4096    # ... bit 12 (excludes bits 5-6): 256 x 256 on 4 waves, one per SIMD (conv_h3.hip)
+# (pg_convh_args.schedule bits 5-6 selected tile families that ABI 0.4 removed; bit 12, the surviving conv_h3 family, is a no-op)
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 

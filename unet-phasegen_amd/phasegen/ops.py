@@ -345,7 +345,7 @@ def conv_wgrad(x, dy, dw, stride, pad, x_act=ACT_NONE, transposed=False, precisi
     return dw
 
 
-# ---- bf16-resident forward path (BASELINE configs[4]; csrc/conv_h.hip) -----------------------------------------------------
+# ---- bf16-resident forward path (BASELINE configs[4]; csrc/conv_h3.hip) ----------------------------------------------------
 H_HEAD = 32      # PG_H_HEAD: zero elements the bf16-resident kernels may read in front of a tensor's first row
 H_TAIL = 40      # zero tail of every row that covers each layer of the U-Net (pg_conv_fwd_h_supported checks a layer's need)
 

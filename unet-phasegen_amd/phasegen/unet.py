@@ -325,7 +325,7 @@ class UNetEngine:
     def forward(self, x, update_stats=True, inference=False):
         """x: (B, C, L) fp32 device tensor -> (B, 2C, L).  BatchNorm is ALWAYS in training mode, as in the
         reference (no .eval() anywhere; demo.py:36 runs batch-of-1 statistics).  ``inference=True`` promises that no
-        backward follows: with precision bf16 the forward then runs on the bf16-resident kernels (csrc/conv_h.hip)."""
+        backward follows: with precision bf16 the forward then runs on the bf16-resident kernels (csrc/conv_h3.hip)."""
         if x.dim() != 3 or x.shape[1] != self.C:
             raise ValueError(f"UNet: expected input (B, {self.C}, L), got {tuple(x.shape)}")
         if not x.is_cuda or x.dtype != torch.float32:
