@@ -551,16 +551,16 @@ def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf1
     # HBM-side stages.  Algorithmic bytes per frame: STFT 2048/512 reads hop samples
     # (2 KB) and writes 1024 bins x [re; im] or [log1p|z|; angle] (8 KB); the ISTFT reads 8 KB and writes 2 KB (+ 2 x 2 KB for the
     # peak normalisation's read-modify-write, which the algorithm needs: the peak is known only after the last sample).
-    def stage(ms, nbytes, kernels):
+    def stage_roof(ms, nbytes, kernels):
         t = [pmc_traffic(k) for k in kernels]
         tr = sum(v for v, _ in t if v) if all(v for v, _ in t) else None
         return {"ms": round(ms, 4), "algorithmic_bytes": nbytes, "TBps": round(nbytes / ms / 1e9, 3), "frac": round(nbytes / ms / 1e9 / PEAK_HBM_TBPS, 4),
                 "bound": "hbm", "peak_TBps": PEAK_HBM_TBPS, "traffic": tr, "traffic_ratio": round(tr / nbytes, 2) if tr else None,
                 "traffic_source": t[0][1], "kernels": kernels}
     nf = nsig * frames
-    stage_roofline = {"stft+polar": stage(stage[0] / 3, nf * (hop * 4 + n_fft * 4), ["stft_w_kernel<false>"]),
-                      "istft": stage(stage[2] / 3, nf * (n_fft * 4 + hop * 4 + 2 * hop * 4),
-                                     ["istft_frames_w_kernel", "istft_ola4_kernel", "istft_peak_normalize_kernel"])}
+    stage_roofline = {"stft+polar": stage_roof(stage[0] / 3, nf * (hop * 4 + n_fft * 4), ["stft_w_kernel<false>"]),
+                      "istft": stage_roof(stage[2] / 3, nf * (n_fft * 4 + hop * 4 + 2 * hop * 4),
+                                          ["istft_ola_w_kernel", "istft_seam_kernel", "istft_peak_normalize_kernel"])}
     return {
         "metric": "spectrogram-frames/sec end to end (STFT + U-Net forward + ISTFT)", "value": world * nsig * frames / sec,
         "unit": "frames/s", "clips_per_s": world * clips / sec, "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -573,11 +573,13 @@ def measure_e2e(torch, dist, world, rank, model, clips, warmup, steps, prec="bf1
         "stage_roofline": stage_roofline, "roofline": roof, "kernels": ks, "device": dev}
 
 
-def measure_train(torch, model, B, C, L, seed, fuse_adam, warmup, steps, contended=False, held=0):
+def measure_train(torch, model, B, C, L, seed, fuse_adam, warmup, steps, contended=False, held=0, hold_shape="rccl+mem"):
     """A full train.py:41-62 step at another shape / update placement on the SAME model (N = 1): ms and frames/s only.
     ``contended``: backward's convolutions take the work split a data-parallel rank uses (engine.contended, set by the Trainer when
-    world > 1).  ``held``: the steps run while a collective-shaped kernel (tools/spin/spin.hip: 256 threads, 113 VGPRs, 32 KB LDS per
-    workgroup) holds that many CUs from a side stream, as RCCL's kernels do during a data-parallel backward."""
+    world > 1).  ``held``: the steps run while a collective-shaped kernel (tools/spin/spin.hip: 256 threads, <= 113 VGPRs, 32 KB LDS
+    per workgroup) holds that many CUs from a side stream, as RCCL's kernels do during a data-parallel backward.  ``hold_shape``:
+    "rccl+mem" = its waves stream memory the whole time (what a collective's data movers do), "rccl" = they spin on dependent-free
+    VALU work, taking every issue slot the conv wave on the same SIMD leaves (the worst case, not a collective's behaviour)."""
     from phasegen.trainer import Trainer
     trainer = Trainer(model, lr=1e-3, fuse_adam=fuse_adam)
     batch = synthetic_batch(torch, B, C, L, seed)
@@ -596,7 +598,7 @@ def measure_train(torch, model, B, C, L, seed, fuse_adam, warmup, steps, contend
             torch.cuda.synchronize()
             main = torch.cuda.current_stream()
             hold = Hold()
-            hold.start(held, shape="rccl", max_us=int(1e6 * (2.0 + steps * 0.4)))
+            hold.start(held, shape=hold_shape, max_us=int(1e6 * (2.0 + steps * (0.4 if hold_shape == "rccl+mem" else 2.0))))
             try:                        # nothing below may wait for the DEVICE (that would wait for the hold kernel): the main stream only
                 t0 = time.perf_counter()
                 for _ in range(steps):
@@ -652,8 +654,13 @@ def other_configs(torch, dist, model, C, L, B):
                                       note="the headline step as every rank of an N > 1 run executes it: Adam NOT fused into the wgrad epilogues "
                                            "(per-layer slices on a side stream) and engine.contended = True (the data-parallel work split)"))
     leg("dp_equivalent_held32", lambda: dict(measure_train(torch, model, B, C, L, 1, False, 2, 5, contended=True, held=32),
-                                             note="the same step while a collective-shaped kernel holds 32 CUs (tools/contention.py, "
-                                                  "profiles/r04_contention.json): a one-GPU stand-in for RCCL's share of the chip"))
+                                             note="the same step while a collective-shaped kernel (256 threads, <= 113 VGPRs, 32 KB LDS, streaming "
+                                                  "memory) holds 32 CUs for its whole duration (tools/contention.py, profiles/r04_contention.json): a "
+                                                  "one-GPU stand-in for RCCL's share of the chip -- pessimistic in time (a 2.45 GB all-reduce occupies "
+                                                  "a fraction of backward, not the whole step)"))
+    leg("dp_equivalent_held32_alu_spin", lambda: dict(measure_train(torch, model, B, C, L, 1, False, 1, 2, contended=True, held=32, hold_shape="rccl"),
+                                                      note="worst case, NOT a collective's behaviour: the held workgroups spin on dependent-free VALU "
+                                                           "work and take every issue slot the conv waves on their SIMDs leave"))
     leg("ref_default", lambda: dict(measure_train(torch, model, 16, C, 128, 3, True, 2, 10),
                                     note="the reference's own defaults, train.py:14-15: batch 16, 1024 bins x 128 frames"))
     leg("fwd", fwd)

@@ -39,7 +39,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--frames", type=int, default=256)
 ap.add_argument("--channels", type=int, default=1024)
-ap.add_argument("--rows", default="0,16:rccl+mem,32:rccl+mem,64:rccl+mem,16:rccl,32:rccl,64:rccl,32:fat",
+ap.add_argument("--rows", default="0,16:rccl+mem,32:rccl+mem,64:rccl+mem,16:rccl,32:rccl,32:fat",
                 help="held workgroups : hold-kernel shape (tools/hold.py: rccl = 113 VGPRs + 32 KB LDS, rccl+mem = that plus a memory "
                      "stream, fat = 194 VGPRs: no conv_raw3 workgroup fits beside it)")
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_contention.json"))
@@ -47,7 +47,9 @@ a = ap.parse_args()
 
 C, L, B = a.channels, a.frames, a.batch
 POLICIES = {"auto": 0, "contended": _lib.SCHED_CONTENDED, "contended+no_raw3": _lib.SCHED_CONTENDED | _lib.SCHED_NO_RAW3,
-            "no_raw3": _lib.SCHED_NO_RAW3}
+            "no_raw3": _lib.SCHED_NO_RAW3, "engine": None, "engine(wgrad auto)": None}
+# "engine": engine.contended = True -- the per-launch table phasegen.unet.CONTENDED_DGRAD / _WGRAD a data-parallel Trainer runs
+# (fine split for the long dgrads, one tile per workgroup for the wgrads); "engine(wgrad auto)": the same with automatic wgrad grids
 torch.manual_seed(0)
 model = UNetModel(C, 2 * C, gpu_ids=[0])
 eng = model.engine
@@ -62,6 +64,17 @@ cells = []
 
 def backward():
     eng.backward(dpred)            # plain order (wgrad, bucket ready, dgrad): what a data-parallel rank enqueues
+
+
+import phasegen.unet as unet_mod  # noqa: E402
+WGRAD_DEFAULT = dict(unet_mod.CONTENDED_WGRAD)
+
+
+def set_policy(name):
+    """Returns the schedule word to install as the thread default for this policy."""
+    eng.contended = name.startswith("engine")
+    unet_mod.CONTENDED_WGRAD.update({k: (0 if name == "engine(wgrad auto)" else WGRAD_DEFAULT[k]) for k in WGRAD_DEFAULT})
+    return 0 if eng.contended else POLICIES[name]
 
 
 def measure(sched):
@@ -95,7 +108,8 @@ for item in a.rows.split(","):
     h, _, shape = item.partition(":")
     rows.append((int(h), shape or "rccl"))
 for held, shape in rows:
-    for name, sched in POLICIES.items():
+    for name in POLICIES:
+        sched = set_policy(name)
         with ops.conv_options(schedule=sched):
             backward()                              # warm (workspaces, first-launch costs) before anything is held
         torch.cuda.synchronize()
@@ -107,7 +121,7 @@ for held, shape in rows:
         info = hold.stop() if held else {"cus_held": 0}
         per, kern = per_launch(timer)
         cell = {"held_workgroups": held, "hold_shape": shape if held else "-", "hold": info, "policy": name,
-                "schedule": sched, "backward_ms": round(clean, 3), "conv_launch_ms_sum": round(sum(per.values()), 3),
+                "schedule": sched, "backward_ms": round(clean, 3), "conv_launch_ms_sum": round(sum(v for k, v in per.items() if not k.startswith("hbm:")), 3),
                 "launch_ms": per, "plan": kern, "wall_s": round(time.time() - t0, 2)}
         if held and (info["held_ms_min"] < busy_s * 1e3 * 0.95 or info["held_ms_max"] > 11900):
             cell["warning"] = "the hold kernel did not cover exactly the measurement (left early, or ran into its time limit)"
@@ -117,7 +131,9 @@ for held, shape in rows:
               f"convs {sum(per.values()):8.2f} ms", flush=True)
 
 # the policy each hold shape implies: per launch, the schedule with the smallest time summed over that shape's rows
-labels = sorted(cells[0]["launch_ms"])
+eng.contended = False
+unet_mod.CONTENDED_WGRAD.update(WGRAD_DEFAULT)
+labels = sorted(k for k in cells[0]["launch_ms"] if not k.startswith("hbm:"))
 policy, table = {}, {}
 for lab in labels:
     table[lab] = {f"{c['policy']}@{c['held_workgroups']}{c['hold_shape'] if c['held_workgroups'] else ''}": c["launch_ms"][lab] for c in cells}

@@ -48,7 +48,10 @@ class Hold:
         if not self.ctl:
             raise RuntimeError("hold: hipHostMalloc of the control block failed")
         self.sink = torch.zeros(4, device=self.device)
-        self.side = torch.cuda.Stream(self.device)
+        # a HIGH-PRIORITY stream: HIP multiplexes streams onto a few hardware queues per priority class, and a normal-priority stream
+        # of the measured program (the Trainer's Adam side stream) that lands in the hold kernel's queue waits behind it for seconds --
+        # first seen as a 937 ms "step" that was really 4 s of queueing (bench_r04_c); another class, another queue
+        self.side = torch.cuda.Stream(self.device, priority=-1)
         self.traffic_bytes = traffic_bytes
         self.buf = None
         self.blocks = 0

@@ -12,7 +12,7 @@ import threading
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, SCHED_CONTENDED  # noqa: F401  (re-exported)
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, SCHED_CONTENDED, SCHED_TILE_PER_WG  # noqa: F401  (re-exported)
 
 
 def _stream():

@@ -40,6 +40,20 @@ BN_OF = {"D1": detgen.BN_D1, "D2": detgen.BN_D2, "U3": detgen.BN_U3, "U2": detge
 # order in which backward produces weight gradients (used for all-reduce bucketing)
 BACKWARD_ORDER = ["U0", "U1", "U2", "U3", "D3", "D2", "D1", "D0"]
 
+# Work split of backward's launches when a collective's kernels share the chip (engine.contended, set by the data-parallel Trainer):
+# pg_conv_args.schedule bits OR-ed into the thread's default, per launch.  From profiles/r04_contention.json (tools/contention.py:
+# every launch of backward at the headline shape beside a collective-shaped kernel -- 256 threads, <= 113 VGPRs, 32 KB LDS, streaming
+# memory -- on 16 / 32 / 64 CUs): the fine stream-K split (PG_SCHED_CONTENDED) bounds the tail of the long F / T launches when CUs are
+# slowed (dgrads of D1, D2, U0, U1, U2: -5 ... -14 % summed over the three hold sizes), the short k = 4 / k = 5 dgrads are as fast
+# or faster on the automatic grids; the wgrads -- thousands of short tiles -- run ONE TILE PER WORKGROUP instead of several whole
+# tiles per persistent workgroup: the hardware dispatcher then balances 8192 units instead of 2048 when some CUs have lost a slot
+# (U0 wgrad paid a flat + 4 ms beside any hold; backward 117.4 against 120.5 - 121.7 ms at 16 / 32 / 64 held CUs, equal on a free
+# chip); the two-waves-per-SIMD kernels (PG_SCHED_NO_RAW3) only win when the co-resident kernel is too fat to share a CU with
+# conv_raw3 (194 VGPRs), which a collective is not.
+CONTENDED_DGRAD = {"U0": ops.SCHED_CONTENDED, "U1": ops.SCHED_CONTENDED, "U2": ops.SCHED_CONTENDED, "U3": 0,
+                   "D3": 0, "D2": ops.SCHED_CONTENDED, "D1": ops.SCHED_CONTENDED}
+CONTENDED_WGRAD = {name: ops.SCHED_TILE_PER_WG for name in BACKWARD_ORDER}
+
 
 def frame_plan(L):
     """Frame counts of every level; raises for lengths the U-Net cannot concatenate (valid: L % 8 == 0, L >= 24)."""
@@ -384,7 +398,8 @@ class UNetEngine:
         a = self.arena
         h = 2 * self.C
         g_out = g_out.contiguous()
-        sched = (ops.current_schedule() | ops.SCHED_CONTENDED) if self.contended else None
+        def sched(table, name):          # per-launch schedule word of a data-parallel backward (None: the thread's default)
+            return (ops.current_schedule() | table[name]) if self.contended else None
 
         def bn_bwd(name, raw, dy, dx):
             key = BN_OF[name]
@@ -396,13 +411,14 @@ class UNetEngine:
             key, kind, s, p = LAYERS[name]
             adam = fused_adam(key) if fused_adam is not None else None       # kept alive until the call has returned
             with ops.timed(name + ".wgrad"):
-                ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"), precision=self.precision, schedule=sched,
-                               adam=adam)
+                ops.conv_wgrad(x, dy, a.g(key), s, p, x_act=act, transposed=(kind == "t"), precision=self.precision,
+                               schedule=sched(CONTENDED_WGRAD, name), adam=adam)
 
         def dgrad(name, dy, dx, **kw):
             key, kind, s, p = LAYERS[name]
             with ops.timed(name + ".dgrad"):
-                ops.conv_dgrad(dy, a.p(key), dx, s, p, transposed=(kind == "t"), precision=self.precision, schedule=sched, **kw)
+                ops.conv_dgrad(dy, a.p(key), dx, s, p, transposed=(kind == "t"), precision=self.precision,
+                               schedule=sched(CONTENDED_DGRAD, name), **kw)
 
         def ready(name):
             if on_grads_ready is not None:
