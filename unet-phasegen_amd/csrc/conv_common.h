@@ -313,15 +313,17 @@ __device__ __forceinline__ int logical_wg(int bid, int G, int w) {
 
 constexpr int ACC_REGS = 128;             // accumulator registers per thread in both tile configurations (8 blocks x 16)
 template <int MB, int NB>
-__device__ __forceinline__ void store_partial(float* ws, int g, int slot, const AccT<MB, NB>& acc, int tid) {
+__device__ __forceinline__ void store_partial(float* ws, int g, int slot, const AccT<MB, NB>& acc, int tid, int nbv = NB) {
     static_assert(MB * NB * 16 == ACC_REGS, "partial-tile slots are sized for 8 blocks per wave");
     float* dst = ws + ((long)(g * 2 + slot) * ACC_REGS) * NT + tid;
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
+            if (j < nbv) {           // (column blocks past the problem's last column are neither written nor, by the fixup, read)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[((i * NB + j) * 16 + r) * NT] = acc.c[i][j][r];
+                for (int r = 0; r < 16; ++r) dst[((i * NB + j) * 16 + r) * NT] = acc.c[i][j][r];
+            }
 }
 
 // fp32 -> bf16, round to nearest even (a plain cast: hipcc emits v_cvt_pk_bf16_f32, NaN stays NaN)

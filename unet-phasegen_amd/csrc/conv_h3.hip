@@ -150,14 +150,18 @@ __device__ __forceinline__ float h3_acc(float v) {
     return x;
 }
 
-__device__ __forceinline__ void store_partial3(float* ws, int g, int slot, const AccT<8, 2>& acc, int tid) {
+// cols_left: columns of the problem from this wave's first column on (wave-uniform).  Column blocks without columns are neither
+// written here nor read by the fixup: at batch 1 (65 ... 14 columns in a 256-wide tile) the partial tiles were 40 % of the bytes moved
+__device__ __forceinline__ void store_partial3(float* ws, int g, int slot, const AccT<8, 2>& acc, int tid, int cols_left) {
     float* dst = ws + ((long)(g * 2 + slot) * H3_REGS) * NT3 + tid;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
+            if (j * 32 < cols_left) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[((i * 2 + j) * 16 + r) * NT3] = h3_acc(acc.c[i][j][r]);
+                for (int r = 0; r < 16; ++r) dst[((i * 2 + j) * 16 + r) * NT3] = h3_acc(acc.c[i][j][r]);
+            }
 }
 
 template <int KW, int S, bool TKIND>
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(NT3, 1) void conv_h3_kernel(const IgemmParams p) {
             H3_EPI(0, 0) H3_EPI(0, 1) H3_EPI(1, 0) H3_EPI(1, 1) H3_EPI(2, 0) H3_EPI(2, 1) H3_EPI(3, 0) H3_EPI(3, 1)
             H3_EPI(4, 0) H3_EPI(4, 1) H3_EPI(5, 0) H3_EPI(5, 1) H3_EPI(6, 0) H3_EPI(6, 1) H3_EPI(7, 0) H3_EPI(7, 1)
 #undef H3_EPI
-        } else store_partial3(p.ws, g, slot, acc, tid);
+        } else store_partial3(p.ws, g, slot, acc, tid, __builtin_amdgcn_readfirstlane(p.B * (TKIND ? p.U : p.Ly) - n0 - (tid >> 6) * 64));
         pos += se - sb;
         slot = 1;
     }
@@ -350,6 +354,7 @@ __global__ __launch_bounds__(NT3) void conv_h3_fixup_kernel(const IgemmParams p,
     const int first = tile * p.nslab, last = first + p.nslab - 1;
     const int g0 = split_owner(sp, first), g1 = split_owner(sp, last);
     if (g0 == g1 && split_lo(sp, g0) <= first && split_lo(sp, g0 + 1) > last) return;
+    if ((tile % p.tilesN) * p.tn_stride + wn * NB * 32 + bj * 32 >= p.B * (KIND == 0 ? p.Ly : p.U)) return;     // a block without columns
     AccT<1, 1> acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc.c[0][0][r] = 0.f;

@@ -55,6 +55,9 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int
     const int first = tile * p.nslab, last = first + p.nslab - 1;
     const int g0 = split_owner(sp, first), g1 = split_owner(sp, last);
     if (g0 == g1 && split_lo(sp, g0) <= first && split_lo(sp, g0 + 1) > last) return;   // computed whole by one workgroup
+    // a 32-column block that starts past the problem's last column holds nothing (few-column problems on the tall tile: the GEMM
+    // kernel did not write it either)
+    if (KIND != 2 && (tile % p.tilesN) * p.tn_stride + (WN == 2 ? wn * (NB - 1) * 32 : (WN == 4 ? wn * (NB * 32) : 0)) + bj * 32 >= p.B * (KIND == 0 ? p.Ly : p.U)) return;
     AccT<1, 1> acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc.c[0][0][r] = 0.f;

@@ -35,9 +35,12 @@ template <int K5> __device__ __forceinline__ constexpr bool k5_virtual(int row_b
     return K5 == 1 ? (row_block == 0 ? (kk & 3) == 3 : (kk & 3) >= 2) : (K5 == 2 ? kk >= 5 : false);
 }
 
+// nbv: column blocks (of 32) of the tile that hold columns at all -- wave-uniform; < 4 only on the tall tile's fp32 pass at few columns
+// (batch-1 inference: 65 / 62 / 29 / 14 columns of 128), where the fragments and MFMAs of the empty blocks are skipped: at N = 65 that
+// pass was MFMA-bound on padding (135 TFLOP/s for 4 blocks), not weight-bound
 template <int TJ, bool DESC, int RS, bool PM, int K5, bool ZERO_VIRTUAL>
 __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
-                                               const int (&bbase)[4], float slopeA, float slopeB, RawFrags& f) {
+                                               const int (&bbase)[4], float slopeA, float slopeB, RawFrags& f, int nbv = 4) {
     const int r = lane & 31, h = lane >> 5;
     if (PM) {
         // phase-major weight image (stride-2 T kernels): row o = 32 floats = the slab's 16 k x 2 phases exactly as they lie in
@@ -65,6 +68,7 @@ __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, con
     const int lanepart = (TJ == 16) ? (DESC ? -8 * h : 8 * h) : (8 / TJ) * h * RS;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
+        if (jb >= nbv) break;
         // descending taps are read as base - (TD - 1) + (TD - 1 - tau): every constant offset stays non-negative and small, so
         // the reads pair into ds_read2_b32 with immediate offsets off ONE address register per column block (negative offsets made
         // hipcc materialise an address per pair)
@@ -102,6 +106,22 @@ __device__ __forceinline__ void raw_load_frags(const float* __restrict__ As, con
     }
 }
 
+// the same with the column blocks as the OUTER loop and everything behind block nbv - 1 skipped by one branch per block
+template <int K5>
+__device__ __forceinline__ void raw_mfma_cols(const RawFrags& f, AccR& acc, int nbv) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j >= nbv) break;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (k5_virtual<K5>(i, kk)) continue;
+                acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk >> 2][kk & 3], f.b[j][kk], acc.c[i][j], 0, 0, 0);
+            }
+    }
+}
+
 template <int BF, int K5>
 __device__ __forceinline__ void raw_mfma(const RawFrags& f, AccR& acc) {
     if (BF) { mfma_low_2x4<BF>(f.a, f.b, acc); return; }
@@ -122,6 +142,13 @@ __device__ __forceinline__ void mma_slab_raw(const float* __restrict__ As, const
     RawFrags f;
     raw_load_frags<TJ, DESC, RS, PM, K5, BF != 0>(As, Bw, lane, wm, bbase, slopeA, slopeB, f);
     raw_mfma<BF, K5>(f, acc);
+}
+template <int TJ, bool DESC, int RS, bool PM, int K5>
+__device__ __forceinline__ void mma_slab_raw_cols(int nbv, const float* __restrict__ As, const float* __restrict__ Bw, int lane, int wm,
+                                                  const int (&bbase)[4], float slopeA, float slopeB, AccR& acc) {
+    RawFrags f;
+    raw_load_frags<TJ, DESC, RS, PM, K5, false>(As, Bw, lane, wm, bbase, slopeA, slopeB, f, nbv);
+    raw_mfma_cols<K5>(f, acc, nbv);
 }
 
 // TKIND false: F (conv fwd / convT dgrad, taps ascend with stride s between columns)
@@ -180,6 +207,8 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
         const int b0 = n0 / Lcol, t0 = n0 - b0 * Lcol;            // sample / position of the tile's first column
         const int nseg = (t0 + TN - 1) / Lcol + 1;
         const int rlen = SC * (TN - 1) + TJ + RG * (nseg - 1);   // floats of a channel window that are ever read
+        constexpr bool SKIPB = WN == 1 && BF == 0;               // tall tile, fp32: column blocks without columns are skipped
+        const int nbv = SKIPB ? __builtin_amdgcn_readfirstlane(min(4, (p.B * Lcol - n0 + 31) / 32)) : 4;
 
         // --- weight-tile gather constants (BYTE offsets) --------------------------------------------------------
         int aoff[AE4], avoff[AE16];
@@ -352,9 +381,15 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             for (int hf = 0; hf < SPB; ++hf) RAW_ISSUE(lds + (cur ^ 1) * SSTG + hf * STG, (sl + SPB + hf) * BK)
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(1)
-            mma_slab_raw<TJ, TKIND, RS, BF, PM, K5>(lds + cur * SSTG, lds + cur * SSTG + TA, lane, wm, bbase, slopeA, slopeB, acc);
-            if (SPB == 2 && sl + 1 < se)
-                mma_slab_raw<TJ, TKIND, RS, BF, PM, K5>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+            if (SKIPB) {         // (ONE code path per kernel: a second copy of the MFMA block beside 128 accumulators spills)
+                mma_slab_raw_cols<TJ, TKIND, RS, PM, K5>(nbv, lds + cur * SSTG, lds + cur * SSTG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+                if (SPB == 2 && sl + 1 < se)
+                    mma_slab_raw_cols<TJ, TKIND, RS, PM, K5>(nbv, lds + cur * SSTG + STG, lds + cur * SSTG + STG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+            } else {
+                mma_slab_raw<TJ, TKIND, RS, BF, PM, K5>(lds + cur * SSTG, lds + cur * SSTG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+                if (SPB == 2 && sl + 1 < se)
+                    mma_slab_raw<TJ, TKIND, RS, BF, PM, K5>(lds + cur * SSTG + STG, lds + cur * SSTG + STG + TA, lane, wm, bbase, slopeA, slopeB, acc);
+            }
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(2)
             __syncthreads();
@@ -366,7 +401,7 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
             if (PM) epilogue_t_pm<2, 4>(p, acc, m0 / 2 + wm * 32, n0 + wn * 128, lane, 0);
             else if (TKIND) epilogue_t<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
             else epilogue_f<S, 2, 4>(p, acc, m0, n0, lane, wm, wn);
-        } else store_partial(p.ws, g, slot, acc, tid);
+        } else store_partial(p.ws, g, slot, acc, tid, nbv);
         pos += se - sb;
         slot = 1;
     }
