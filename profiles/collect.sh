@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects everything under profiles/ that comes from the GPU box, from the CURRENT build.  Run on the box from the repository
-# root, e.g.   gpurun --timeout 1200 -- 'bash profiles/collect.sh r03'
-# then condense here with   bash profiles/collect.sh --summarize r03   (copies the small per-kernel tables into profiles/).
+# root, e.g.   gpurun --timeout 1200 -- 'bash profiles/collect.sh r04'
+# then condense here with   bash profiles/collect.sh --summarize r04   (copies the small per-kernel tables into profiles/).
 #
 # Rules this script encodes (MI355X_MICROARCH.md, rocprofv3 PMC slots; the round-1 and round-2 aborts "error code 38: Request
 # exceeds the capabilities of the hardware to collect" came from several TCC-derived counters in one --pmc pass):
@@ -11,7 +11,7 @@
 #   * a counter the installed rocprofv3 does not know is skipped (its pass fails fast with a message), never retried.
 set -o pipefail
 if [ "$1" = "--summarize" ]; then
-    tag=${2:-r03}
+    tag=${2:-r04}
     here=$(cd "$(dirname "$0")" && pwd)
     for cfg in train e2e fwd; do
         sfx=$([ $cfg = train ] && echo "" || echo "_$cfg")
@@ -21,11 +21,13 @@ if [ "$1" = "--summarize" ]; then
     done
     exit 0
 fi
-tag=${1:-r03}
+tag=${1:-r04}
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 mkdir -p gpurun_out
-TCC_COUNTERS="FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum TCC_BUBBLE_sum"
+# (round 3 also collected TCC_EA0_RDREQ* / WRREQ* / BUBBLE: RDREQ_DRAM equals RDREQ on every kernel -- it does not separate Infinity-Cache
+# hits from HBM reads -- so they were dropped; profiles/r03_pmc_summary.json keeps them)
+TCC_COUNTERS="FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 SQ_PASS="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 run_cfg() {     # $1 = name, rest = bench.py arguments of the short (counter) run; the traced run uses --steps 10 --warmup 3
     cfg=$1; shift
