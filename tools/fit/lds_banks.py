@@ -37,3 +37,15 @@ pats = {
 }
 for name, (fn, n) in pats.items():
     print(f"{worst(fn, n)}-way  {name}")
+# the 512-point transform (n_fft = 1024): 8 points per lane, 8 x 8 x 8, pads 72 / 68, output in natural order
+pats8 = {
+    "P8 input read n = l + 64 r": (lambda l, r: l + 64 * r, 8),
+    "P8 ex1 write 72 k1 + l": (lambda l, r: 72 * r + l, 8),
+    "P8 ex1 read  72 (l >> 3) + (l & 7) + 8 r": (lambda l, r: 72 * (l >> 3) + (l & 7) + 8 * r, 8),
+    "P8 ex2 write 68 (l & 7) + (l >> 3) + 8 k2": (lambda l, r: 68 * (l & 7) + (l >> 3) + 8 * r, 8),
+    "P8 ex2 read  68 j + l": (lambda l, r: 68 * r + l, 8),
+    "P8 T1 read [k1][l]": (lambda l, r: 64 * r + l, 8),
+    "P8 T2 read [k2][j = l & 7]": (lambda l, r: 8 * r + (l & 7), 8),
+}
+for name, (fn, n) in pats8.items():
+    print(f"{worst(fn, n)}-way  {name}")

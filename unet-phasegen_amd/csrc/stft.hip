@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void istft_peak_normalize_kernel(float* audio,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Wave-per-frame transforms (round 4; n_fft = 2048, the reference's default: preproc_mdb.py:202-204).
+// Wave-per-frame transforms (round 4; n_fft = 2048, the reference's default: preproc_mdb.py:202-204, and n_fft = 1024).
 // The radix-4 Stockham passes above spread one frame over a whole workgroup: 5 passes = 5 LDS round trips + 5 workgroup barriers per
 // group of frames, 2 waves per SIMD (72 KB of LDS per workgroup) -- measured latency-bound, 3x off its VALU time.  Here ONE WAVE owns
 // one frame: the 1024-point complex transform behind the real 2048-point one is 16 points per lane, factored 16 x 16 x 4:
@@ -494,7 +494,21 @@ __global__ __launch_bounds__(256) void istft_peak_normalize_kernel(float* audio,
 // (bins, frames) layout are touched 32 B at a time -- at 16 B the row stores alone were 28 of 74 us, one L2 request per 16 B piece)
 // meet twice per group.  78.3 KB of LDS per workgroup: 2 workgroups = 16 waves per CU.
 // Layouts (pads 68 / 264) are bank-conflict-free for every access: tools/fit/lds_banks.py.
-constexpr int WREG = 1088;                                  // float2 per wave region: 16 sub-transforms x (64 + 4 pad)
+// P points per lane (16: the 1024-point transform of n_fft = 2048; 8: the 512-point one of n_fft = 1024, factored 8 x 8 x 8 with
+// pads 72 / 68 and the output already in natural order: X[lane + 64 r] in register r)
+template <int P> struct WaveFft;
+template <> struct WaveFft<16> {
+    static constexpr int M = 1024, REG = 1088, T1N = 1024, T2N = 64;       // REG: float2 per wave region, 16 sub-transforms x (64 + 4 pad)
+    __device__ static __forceinline__ int out(int lane, int reg) { return (lane & 15) + 16 * (4 * (reg >> 2) + (lane >> 4)) + 256 * (reg & 3); }
+    __device__ static __forceinline__ constexpr int rot_out(int reg) { return (reg >> 2) + 4 * (reg & 3); }   // theta(out) - theta(lane), units of pi / 8
+    static constexpr float CD = 0.999995293809576172f, SD = 0.00306795676296597627f;     // cos, sin (pi / 1024)
+};
+template <> struct WaveFft<8> {
+    static constexpr int M = 512, REG = 576, T1N = 512, T2N = 64;          // 8 x (64 + 8 pad)
+    __device__ static __forceinline__ int out(int lane, int reg) { return lane + 64 * reg; }
+    __device__ static __forceinline__ constexpr int rot_out(int reg) { return 2 * reg; }
+    static constexpr float CD = 0.999981175282601109f, SD = 0.00613588464915447536f;     // cos, sin (pi / 512)
+};
 
 __device__ __forceinline__ void wave_order() {              // compiler-level ordering of a wave's own LDS traffic (no instruction)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -524,29 +538,45 @@ template <int DIR> __device__ __forceinline__ void radix16(float2 (&v)[16]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) radix4<DIR>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);   // over r0: v[4 q + s] = X[q + 4 s]
 }
-__device__ __forceinline__ int r16_out(int i) { return (i >> 2) + 4 * (i & 3); }      // index k of the value radix16 leaves in v[i]
+// 8-point transform in place: v[m] = X[2 m], v[4 + m] = X[2 m + 1] (m = 0..3)
+template <int DIR> __device__ __forceinline__ void radix8(float2 (&v)[8]) {
+    constexpr float R2 = 0.707106781186547524f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float2 a = v[r], b = v[r + 4];
+        v[r] = make_float2(a.x + b.x, a.y + b.y);
+        v[r + 4] = make_float2(a.x - b.x, a.y - b.y);
+    }
+    v[5] = tmul<DIR>(v[5], R2, R2); v[6] = tmul<DIR>(v[6], 0.f, 1.f); v[7] = tmul<DIR>(v[7], -R2, R2);      // (a - b) w8^r
+    radix4<DIR>(v[0], v[1], v[2], v[3]);
+    radix4<DIR>(v[4], v[5], v[6], v[7]);
+}
+template <int P> __device__ __forceinline__ constexpr int rP_out(int i) { return P == 16 ? (i >> 2) + 4 * (i & 3) : (i < 4 ? 2 * i : 2 * (i - 4) + 1); }
+template <int DIR> __device__ __forceinline__ void radixP(float2 (&v)[16]) { radix16<DIR>(v); }
+template <int DIR> __device__ __forceinline__ void radixP(float2 (&v)[8]) { radix8<DIR>(v); }
 
-// T1[k1][l] = exp(-2 pi i l k1 / 1024), T2[k2][j] = exp(-2 pi i j k2 / 64): built once per workgroup
-__device__ void wave_fft_tables(float2* T1, float2* T2) {
-    for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+// T1[k1][l] = exp(-2 pi i l k1 / M), T2[k2][j] = exp(-2 pi i j k2 / 64) (P = 16: j < 4; P = 8: j < 8): built once per workgroup
+template <int P> __device__ void wave_fft_tables(float2* T1, float2* T2) {
+    constexpr int M = WaveFft<P>::M, J = P == 16 ? 4 : 8;
+    for (int e = threadIdx.x; e < M; e += blockDim.x) {
         float sn, cs;
-        sincospif(-2.0f * (float)((e & 63) * (e >> 6)) / 1024.0f, &sn, &cs);
+        sincospif(-2.0f * (float)((e & 63) * (e >> 6)) / (float)M, &sn, &cs);
         T1[e] = make_float2(cs, sn);
     }
     for (int e = threadIdx.x; e < 64; e += blockDim.x) {
         float sn, cs;
-        sincospif(-2.0f * (float)((e & 3) * (e >> 2)) / 64.0f, &sn, &cs);
+        sincospif(-2.0f * (float)((e % J) * (e / J)) / 64.0f, &sn, &cs);
         T2[e] = make_float2(cs, sn);
     }
 }
 
-// in: v[r] = z[lane + 64 r].  out: v[4 q + k3] = Z[k1 + 16 k2 + 256 k3], k1 = lane & 15, k2 = 4 q + (lane >> 4)   (unnormalised)
+// in: v[r] = z[lane + 64 r].  out: v[reg] = Z[WaveFft<P>::out(lane, reg)]   (unnormalised)
 template <int DIR>
-__device__ __forceinline__ void wave_fft1024(float2 (&v)[16], float2* reg, const float2* T1, const float2* T2, int lane) {
+__device__ __forceinline__ void wave_fft(float2 (&v)[16], float2* reg, const float2* T1, const float2* T2, int lane) {
     radix16<DIR>(v);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int k1 = r16_out(i);
+        const int k1 = rP_out<16>(i);
         if (k1) { const float2 w = T1[64 * k1 + lane]; v[i] = tmul<DIR>(v[i], w.x, -w.y); }   // (the table holds exp(-i theta): sin = -w.y)
         reg[68 * k1 + lane] = v[i];
     }
@@ -558,7 +588,7 @@ __device__ __forceinline__ void wave_fft1024(float2 (&v)[16], float2* reg, const
     radix16<DIR>(v);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int k2 = r16_out(i);
+        const int k2 = rP_out<16>(i);
         if (k2) { const float2 w = T2[4 * k2 + j]; v[i] = tmul<DIR>(v[i], w.x, -w.y); }
         reg[264 * j + kb + 16 * k2] = v[i];
     }
@@ -572,27 +602,60 @@ __device__ __forceinline__ void wave_fft1024(float2 (&v)[16], float2* reg, const
 #pragma unroll
     for (int q = 0; q < 4; ++q) radix4<DIR>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
+template <int DIR>
+__device__ __forceinline__ void wave_fft(float2 (&v)[8], float2* reg, const float2* T1, const float2* T2, int lane) {
+    radix8<DIR>(v);                                           // over r: v[i] = y[k1], k1 = rP_out<8>(i)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k1 = rP_out<8>(i);
+        if (k1) { const float2 w = T1[64 * k1 + lane]; v[i] = tmul<DIR>(v[i], w.x, -w.y); }
+        reg[72 * k1 + lane] = v[i];
+    }
+    wave_order();
+    const int kb = lane >> 3, j = lane & 7;                   // lane (k1, j) gets l = j + 8 r' of sub-transform k1
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = reg[72 * kb + j + 8 * r];
+    wave_order();
+    radix8<DIR>(v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k2 = rP_out<8>(i);
+        if (k2) { const float2 w = T2[8 * k2 + j]; v[i] = tmul<DIR>(v[i], w.x, -w.y); }
+        reg[68 * j + kb + 8 * k2] = v[i];
+    }
+    wave_order();
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) v[jj] = reg[68 * jj + lane];          // lane = k1 + 8 k2 holds the eight j of its pair
+    wave_order();
+    radix8<DIR>(v);                                           // over j: v[i] = X[lane + 64 k3], k3 = rP_out<8>(i)
+    float2 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[rP_out<8>(i)] = v[i];       // (compile-time permutation: register k3 holds X[lane + 64 k3])
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = t[i];
+}
 
-// Periodic Hann window of length 2048 at the sample pair (2 m, 2 m + 1) from (cos, sin) of theta_m = 2 pi m / 1024, which the lanes
-// compose from a per-lane base angle and compile-time rotations (multiples of pi / 8 and of pi / 2): 32 window values per frame
-// cost ~130 flops instead of 32 registers per lane held for the whole kernel.
+// Periodic Hann window of length n_fft at the sample pair (2 m, 2 m + 1) from (cos, sin) of theta_m = 2 pi m / M, which the lanes
+// compose from a per-lane base angle and compile-time rotations (multiples of pi / 8): the window values of a frame cost ~8 flops
+// each instead of 2 P registers per lane held for the whole kernel.
 constexpr float W8C[16] = {1.f, 0.923879532511286756f, 0.707106781186547524f, 0.382683432365089772f, 0.f, -0.382683432365089772f,
                            -0.707106781186547524f, -0.923879532511286756f, -1.f, -0.923879532511286756f, -0.707106781186547524f,
                            -0.382683432365089772f, 0.f, 0.382683432365089772f, 0.707106781186547524f, 0.923879532511286756f};
 constexpr float W8S[16] = {0.f, 0.382683432365089772f, 0.707106781186547524f, 0.923879532511286756f, 1.f, 0.923879532511286756f,
                            0.707106781186547524f, 0.382683432365089772f, 0.f, -0.382683432365089772f, -0.707106781186547524f,
                            -0.923879532511286756f, -1.f, -0.923879532511286756f, -0.707106781186547524f, -0.382683432365089772f};
-__device__ __forceinline__ void hann_pair(float c, float s, float& w0, float& w1) {       // (c, s) = (cos, sin) theta_m
-    constexpr float CD = 0.999995293809576172f, SD = 0.00306795676296597627f;             // cos, sin (pi / 1024): half a pair further
+// window pair at theta = base + rot pi / 8, base given as (cb, sb)
+template <int P> __device__ __forceinline__ void hann_pair(float cb, float sb, int rot, float& w0, float& w1) {
+    const float c = __fmaf_rn(cb, W8C[rot & 15], -(sb * W8S[rot & 15])), s = __fmaf_rn(sb, W8C[rot & 15], cb * W8S[rot & 15]);
     w0 = 0.5f - 0.5f * c;
-    w1 = 0.5f - 0.5f * __fmaf_rn(c, CD, -(s * SD));
+    w1 = 0.5f - 0.5f * __fmaf_rn(c, WaveFft<P>::CD, -(s * WaveFft<P>::SD));       // half a pair further: + pi / M
 }
 
 constexpr int NW = 8;                                       // waves = frames per workgroup: row segments of 8 frames (32 B)
-constexpr int WT = NW * 64;                                 // threads; thread tid owns the bin pair (k, 1024 - k), k = 1 + tid
+constexpr int WT = NW * 64;                                 // threads; a thread pair owns the bin pairs (k, M - k), k = 1 + (tid >> 1) + 256 i
 
-// dynamic LDS of the wave-per-frame kernels: NW wave regions + T1 + T2 (78.3 KB: two workgroups = 16 waves per CU)
-constexpr size_t WAVE_LDS = (size_t)(NW * WREG + 1024 + 64) * sizeof(float2);
+// dynamic LDS of the wave-per-frame kernels: NW wave regions + T1 + T2 (P = 16: 78.3 KB, two workgroups = 16 waves per CU; P = 8: 41.5 KB)
+template <int P> constexpr size_t wave_lds() { return (size_t)(NW * WaveFft<P>::REG + WaveFft<P>::T1N + WaveFft<P>::T2N) * sizeof(float2); }
 
 // one output row, 4 of the group's 8 frames (half = 0 / 1): as stft_store_row
 __device__ __forceinline__ void stft_store_row4(const pg_stft_args& a, float* o_re, float* o_im, long row, int half, int nfr, bool vec,
@@ -621,29 +684,30 @@ __device__ __forceinline__ void stft_store_row4(const pg_stft_args& a, float* o_
     }
 }
 
-// STFT, n_fft = 2048: wave w of a workgroup transforms frame t0 + w of its group of NW frames; the split X[k] = E[k] + w^k O[k], the
+// STFT, n_fft = 128 P: wave w of a workgroup transforms frame t0 + w of its group of NW frames; the split X[k] = E[k] + w^k O[k], the
 // optional polar epilogue and the row stores (two 16 B pieces = 32 B per row and workgroup) are the workgroup-wide phase, reading the
 // waves' spectra from LDS.
-template <bool CHUNKED>
+template <bool CHUNKED, int P>
 __global__ __launch_bounds__(WT, CHUNKED ? 2 : 4) void stft_w_kernel(const pg_stft_args a) {
+    using W = WaveFft<P>;
     extern __shared__ __attribute__((aligned(16))) float2 wsm[];
-    float2 (*regs)[WREG] = (float2 (*)[WREG])wsm;
-    float2* T1 = wsm + NW * WREG; float2* T2 = T1 + 1024;
-    constexpr int N = 2048, M = 1024;
+    float2 (*regs)[W::REG] = (float2 (*)[W::REG])wsm;
+    float2* T1 = wsm + NW * W::REG; float2* T2 = T1 + W::T1N;
+    constexpr int M = W::M, N = 2 * M, PAIRS = M / 512;       // bin pairs per thread in the split phase
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int groups = (a.n_frames + NW - 1) / NW, total = a.n_signals * groups;
-    wave_fft_tables(T1, T2);
-    float cb, sb, sc, ss;                                     // (cos, sin)(2 pi lane / 1024): base of this lane's window angles; split factor w^k
-    sincospif(2.0f * (float)lane / 1024.0f, &sb, &cb);
-    float sc2, ss2;                                           // split factors of this thread's two bin pairs k = 1 + (tid >> 1) + 256 i
+    wave_fft_tables<P>(T1, T2);
+    float cb, sb, sc, ss;                                     // (cos, sin)(2 pi lane / M): base of this lane's window angles; split factor w^k
+    sincospif(2.0f * (float)lane / (float)M, &sb, &cb);
+    float sc2 = 0.f, ss2 = 0.f;                               // split factors of this thread's bin pairs k = 1 + (tid >> 1) + 256 i
     sincospif(-(float)(1 + (int)(threadIdx.x >> 1)) / (float)M, &ss, &sc);
-    sincospif(-(float)(257 + (int)(threadIdx.x >> 1)) / (float)M, &ss2, &sc2);
+    if (PAIRS > 1) sincospif(-(float)(257 + (int)(threadIdx.x >> 1)) / (float)M, &ss2, &sc2);
     const bool vec2 = !CHUNKED && ((a.hop | a.n_samples) & 1) == 0 && (((uintptr_t)a.y) & 7) == 0;   // sample pairs are 8 B aligned
     const bool vec4 = (a.n_frames & 3) == 0 && (((uintptr_t)a.out) & 15) == 0;               // row segments are 16 B aligned
     // This wave's frame of group g as RAW sample pairs v[r] = (y[2 m], y[2 m + 1]), m = lane + 64 r (reflect padding by index math: the
     // bit-exact part of the contract).  Issued one group AHEAD, into the registers the finished transform has just vacated, so the
     // samples travel while the workgroup splits, converts and stores the current group.
-    float2 v[16];
+    float2 v[P];
     auto load_frame = [&](int g) {
         const int sig = g / groups, t0 = (g - sig * groups) * NW;
         if (wave >= min(NW, a.n_frames - t0)) return;
@@ -654,9 +718,9 @@ __global__ __launch_bounds__(WT, CHUNKED ? 2 : 4) void stft_w_kernel(const pg_st
         const int start = (t0 + wave) * a.hop - M;                              // frame tap k sits at sample start + k
         const bool inside = start >= 0 && start + N <= a.n_samples;
         int lo = lane;
-        asm volatile("" : "+v"(lo));                          // (opaque: keeps 16 per-lane sample offsets out of the loop-invariant registers)
+        asm volatile("" : "+v"(lo));                          // (opaque: keeps the per-lane sample offsets out of the loop-invariant registers)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < P; ++r) {
             const int p = start + 2 * (lo + 64 * r);
             float v0, v1;
             if (PG_W_ABL & 1) { v0 = (float)p; v1 = 1.f; }
@@ -675,19 +739,16 @@ __global__ __launch_bounds__(WT, CHUNKED ? 2 : 4) void stft_w_kernel(const pg_st
         const int nfr = min(NW, a.n_frames - t0);
         if (wave < nfr) {
             float cbo = cb, sbo = sb;
-            asm volatile("" : "+v"(cbo), "+v"(sbo));          // (opaque: or the 32 window values are hoisted out of the loop and spilled)
+            asm volatile("" : "+v"(cbo), "+v"(sbo));          // (opaque: or the window values are hoisted out of the loop and spilled)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float w0, w1;                                                   // m = lane + 64 r: theta = base + r pi / 8
-                hann_pair(__fmaf_rn(cbo, W8C[r], -(sbo * W8S[r])), __fmaf_rn(sbo, W8C[r], cbo * W8S[r]), w0, w1);
+            for (int r = 0; r < P; ++r) {
+                float w0, w1;                                                   // m = lane + 64 r: theta = base + r 2 pi / P
+                hann_pair<P>(cbo, sbo, r * (16 / P), w0, w1);
                 v[r] = make_float2(v[r].x * w0, v[r].y * w1);
             }
-            if (!(PG_W_ABL & 2)) wave_fft1024<1>(v, regs[wave], T1, T2, lane);
-            const int k1 = lane & 15, kh = lane >> 4;
+            if (!(PG_W_ABL & 2)) wave_fft<1>(v, regs[wave], T1, T2, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int k3 = 0; k3 < 4; ++k3) regs[wave][k1 + 16 * (4 * q + kh) + 256 * k3] = v[4 * q + k3];     // natural order
+            for (int r = 0; r < P; ++r) regs[wave][W::out(lane, r)] = v[r];     // natural order
         }
         lds_barrier();
         if (gw.g + gw.step < gw.end) load_frame(gw.g + gw.step);              // (v is free: the spectra are in LDS)
@@ -695,15 +756,15 @@ __global__ __launch_bounds__(WT, CHUNKED ? 2 : 4) void stft_w_kernel(const pg_st
         float* o_im = o_re + (long)M * a.n_frames;
         if (PG_W_ABL & 8) { lds_barrier(); continue; }
         // Lanes 2 i and 2 i + 1 take the two 16 B halves of the SAME rows, so a wave's store instruction covers 32 rows x 32 contiguous
-        // bytes (one L2 request per row instead of two); a thread does two bin pairs: k = 1 + (tid >> 1) + 256 i.
+        // bytes (one L2 request per row instead of two); a thread does PAIRS bin pairs: k = 1 + (tid >> 1) + 256 i.
         int tid_o = threadIdx.x;
         asm volatile("" : "+v"(tid_o));                       // (opaque: the row addresses below are computed here, not carried across the barrier)
         const int half = tid_o & 1;
         if (4 * half < nfr) {
             const bool vec = vec4 && 4 * half + 4 <= nfr;
 #pragma unroll 1
-            for (int i = 0; i < 2; ++i) {                                     // bins k and M-k from Z[k], Z[M-k]; DC dropped
-                const int k = 1 + (tid_o >> 1) + 256 * i;                     // 1 .. 512
+            for (int i = 0; i < PAIRS; ++i) {                                 // bins k and M-k from Z[k], Z[M-k]; DC dropped
+                const int k = 1 + (tid_o >> 1) + 256 * i;                     // 1 .. M / 2
                 const float sn = i ? ss2 : ss, cs = i ? sc2 : sc;
                 float rk[4], ik[4], rm[4], im[4];
 #pragma unroll
@@ -729,83 +790,78 @@ __global__ __launch_bounds__(WT, CHUNKED ? 2 : 4) void stft_w_kernel(const pg_st
     }
 }
 
-// ISTFT frames, n_fft = 2048: the workgroup builds the NW half-length spectra Z_f[k] (natural order) together -- rows are read as
-// two 16 B pieces (32 B per row and workgroup) --, then every wave inverts its own frame and stores it windowed, 8 B per lane in
-// runs of 128 B.
+// the workgroup-wide build of the NW half-length spectra Z_f[k] (natural order) from the spectrum rows of one group: lanes 2 i and
+// 2 i + 1 read the two 16 B halves of the same rows (a wave's load instruction covers 32 rows x 32 contiguous bytes)
+template <int P>
+__device__ __forceinline__ void istft_build_w(const pg_istft_args& a, float2 (*regs)[WaveFft<P>::REG], int sig, int t0, int nfr, bool vec4,
+                                              float sc, float ss, float sc2, float ss2) {
+    constexpr int M = WaveFft<P>::M, PAIRS = M / 512;
+    const int half = threadIdx.x & 1, n4 = nfr - 4 * half;
+    if (n4 <= 0) return;
+    const float* pa = a.a + (long)sig * a.a_bs + t0 + 4 * half;
+    const float* pb = a.b + (long)sig * a.b_bs + t0 + 4 * half;
+    const bool vec = vec4 && n4 >= 4;
+#pragma unroll 1
+    for (int i = 0; i < PAIRS; ++i) {                         // Z[k] = E[k] + i O[k] (see istft_frames4_kernel)
+        const int k = 1 + (int)(threadIdx.x >> 1) + 256 * i;
+        const float sn = i ? ss2 : ss, cs = i ? sc2 : sc;
+        float2 Xk[SF], Xm[SF];
+        istft_row(a, pa, pb, k, n4, vec, Xk);
+        istft_row(a, pa, pb, k == M - k ? M : M - k, n4, vec, Xm);           // (the self-paired threads read the Nyquist row here)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float2 Xo = k == M - k ? Xk[f] : Xm[f];
+            const float2 E = make_float2(0.5f * (Xk[f].x + Xo.x), 0.5f * (Xk[f].y - Xo.y));
+            const float2 D = make_float2(0.5f * (Xk[f].x - Xo.x), 0.5f * (Xk[f].y + Xo.y));
+            const float2 O = cmul(D, make_float2(cs, sn));
+            regs[4 * half + f][k] = make_float2(E.x - O.y, E.y + O.x);
+            if (k != M - k) regs[4 * half + f][M - k] = make_float2(E.x + O.y, O.x - E.y);
+            else regs[4 * half + f][0] = make_float2(0.5f * Xm[f].x, -0.5f * Xm[f].x);      // Z[0]: X[0] = 0, X[M] real
+        }
+    }
+}
+
+// ISTFT frames, n_fft = 128 P: the workgroup builds the spectra together, then every wave inverts its own frame and stores it
+// windowed, 8 B per lane.  (A prefetch of the next group's rows during the transforms needs 32 more registers than two workgroups per
+// CU leave: measured 151 us at one workgroup per CU with it against 125 us without.)
+template <int P>
 __global__ __launch_bounds__(WT, 4) void istft_frames_w_kernel(const pg_istft_args a, float* frames) {
+    using W = WaveFft<P>;
     extern __shared__ __attribute__((aligned(16))) float2 wsm[];
-    float2 (*regs)[WREG] = (float2 (*)[WREG])wsm;
-    float2* T1 = wsm + NW * WREG; float2* T2 = T1 + 1024;
-    constexpr int N = 2048, M = 1024;
+    float2 (*regs)[W::REG] = (float2 (*)[W::REG])wsm;
+    float2* T1 = wsm + NW * W::REG; float2* T2 = T1 + W::T1N;
+    constexpr int M = W::M, N = 2 * M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int groups = (a.n_frames + NW - 1) / NW, total = a.n_signals * groups;
-    wave_fft_tables(T1, T2);
-    // window (times 1 / M) at the points this lane ends up with: m = k1 + 16 (4 q + kh) + 256 k3 in register 4 q + k3,
-    // k1 = lane & 15, kh = lane >> 4, i.e. k1 + 16 kh = lane
-    float cb, sb, sc, ss;                                     // (cos, sin)(2 pi lane / 1024): theta_m = base + q pi / 8 + k3 pi / 2
-    sincospif(2.0f * (float)lane / 1024.0f, &sb, &cb);
+    wave_fft_tables<P>(T1, T2);
+    float cb, sb, sc, ss, sc2 = 0.f, ss2 = 0.f;               // (cos, sin)(2 pi lane / M): base of the window angles of this lane's outputs
+    sincospif(2.0f * (float)lane / (float)M, &sb, &cb);
     const float inv = 1.0f / (float)M;
-    float sc2, ss2;                                           // exp(+2 pi i k / n_fft) of this thread's two bin pairs k = 1 + (tid >> 1) + 256 i
-    sincospif((float)(1 + (int)(threadIdx.x >> 1)) / (float)M, &ss, &sc);
-    sincospif((float)(257 + (int)(threadIdx.x >> 1)) / (float)M, &ss2, &sc2);
+    sincospif((float)(1 + (int)(threadIdx.x >> 1)) / (float)M, &ss, &sc);          // exp(+2 pi i k / n_fft) of this thread's bin pairs
+    if (M > 512) sincospif((float)(257 + (int)(threadIdx.x >> 1)) / (float)M, &ss2, &sc2);
     const bool vec4 = (a.n_frames & 3) == 0 && ((a.a_bs | a.b_bs) & 3) == 0 && ((((uintptr_t)a.a) | ((uintptr_t)a.b)) & 15) == 0;
-    // (A prefetch of the next group's rows during the transforms needs 32 more registers than two workgroups per CU leave: measured
-    // 151 us at one workgroup per CU with it against 125 us without.)  Lanes 2 i and 2 i + 1 read the two 16 B halves of the same rows (a wave's
-    // load instruction covers 32 rows x 32 contiguous bytes); a thread does two bin pairs: k = 1 + (tid >> 1) + 256 i.
-    const int half = threadIdx.x & 1;
     __syncthreads();
     for (GroupWalk gw = group_walk(total); gw.g < gw.end; gw.g += gw.step) {
         const int sig = gw.g / groups, t0 = (gw.g - sig * groups) * NW;
         const int nfr = min(NW, a.n_frames - t0);
-        const int n4 = nfr - 4 * half;
-        if (n4 > 0) {                                         // Z[k] = E[k] + i O[k] (see istft_frames4_kernel)
-            const float* pa = a.a + (long)sig * a.a_bs + t0 + 4 * half;
-            const float* pb = a.b + (long)sig * a.b_bs + t0 + 4 * half;
-            const bool vec = vec4 && n4 >= 4;
-#pragma unroll 1
-            for (int i = 0; i < 2; ++i) {
-                const int k = 1 + (int)(threadIdx.x >> 1) + 256 * i;
-                const float sn = i ? ss2 : ss, cs = i ? sc2 : sc;
-                float2 Xk[SF], Xm[SF];
-                istft_row(a, pa, pb, k, n4, vec, Xk);
-                istft_row(a, pa, pb, k == M - k ? M : M - k, n4, vec, Xm);   // (the self-paired threads read the Nyquist row here)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const float2 Xo = k == M - k ? Xk[f] : Xm[f];
-                    const float2 E = make_float2(0.5f * (Xk[f].x + Xo.x), 0.5f * (Xk[f].y - Xo.y));
-                    const float2 D = make_float2(0.5f * (Xk[f].x - Xo.x), 0.5f * (Xk[f].y + Xo.y));
-                    const float2 O = cmul(D, make_float2(cs, sn));
-                    regs[4 * half + f][k] = make_float2(E.x - O.y, E.y + O.x);
-                    if (k != M - k) regs[4 * half + f][M - k] = make_float2(E.x + O.y, O.x - E.y);
-                    else regs[4 * half + f][0] = make_float2(0.5f * Xm[f].x, -0.5f * Xm[f].x);      // Z[0]: X[0] = 0, X[M] real
-                }
-            }
-        }
+        istft_build_w<P>(a, regs, sig, t0, nfr, vec4, sc, ss, sc2, ss2);
         lds_barrier();
         if (wave < nfr) {
-            float2 v[16];
+            float2 v[P];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = regs[wave][lane + 64 * r];
+            for (int r = 0; r < P; ++r) v[r] = regs[wave][lane + 64 * r];
             wave_order();
-            if (!(PG_W_ABL & 2)) wave_fft1024<-1>(v, regs[wave], T1, T2, lane);
+            if (!(PG_W_ABL & 2)) wave_fft<-1>(v, regs[wave], T1, T2, lane);
             int lo = lane;
             asm volatile("" : "+v"(lo));                      // (opaque: keeps the store addresses out of the loop-invariant registers)
-            const int k1 = lo & 15, kh = lo >> 4;
             float2* dst = (float2*)(frames + ((long)sig * a.n_frames + t0 + wave) * N);
             float cbo = cb, sbo = sb;
-            asm volatile("" : "+v"(cbo), "+v"(sbo));          // (opaque: or the 32 window values are hoisted out of the loop)
+            asm volatile("" : "+v"(cbo), "+v"(sbo));          // (opaque: or the window values are hoisted out of the loop)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float cq = __fmaf_rn(cbo, W8C[q], -(sbo * W8S[q])), sq = __fmaf_rn(sbo, W8C[q], cbo * W8S[q]);     // + q pi / 8
-#pragma unroll
-                for (int k3 = 0; k3 < 4; ++k3) {
-                    const float c = k3 == 0 ? cq : k3 == 1 ? -sq : k3 == 2 ? -cq : sq;                              // + k3 pi / 2
-                    const float sn = k3 == 0 ? sq : k3 == 1 ? cq : k3 == 2 ? -sq : -cq;
-                    float w0, w1;
-                    hann_pair(c, sn, w0, w1);
-                    const float2 z = v[4 * q + k3];
-                    dst[k1 + 16 * (4 * q + kh) + 256 * k3] = make_float2(z.x * (inv * w0), z.y * (inv * w1));
-                }
+            for (int r = 0; r < P; ++r) {
+                float w0, w1;
+                hann_pair<P>(cbo, sbo, W::rot_out(r), w0, w1);
+                dst[W::out(lo, r)] = make_float2(v[r].x * (inv * w0), v[r].y * (inv * w1));
             }
         }
         lds_barrier();
@@ -813,18 +869,19 @@ __global__ __launch_bounds__(WT, 4) void istft_frames_w_kernel(const pg_istft_ar
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// ISTFT at n_fft = 2048, hop = 512 with the overlap-add INSIDE the transform kernel (round 4): a workgroup's eight windowed frames
-// never leave LDS.  Of the 8 hop + (n_fft - hop) output positions they touch, blocks 3..7 (of 512 samples) are complete and are
-// finalised on the spot (window-sum-square division, n_fft / 2 trim, peak, one 16 B store per lane); blocks 0..2 ("head") still miss
-// the previous group's last three frames and blocks 8..10 ("tail") are this group's share of the next group's head: the head is
-// stored to the audio buffer as a partial sum, the tail to a small workspace (6 KB per group), and a seam kernel adds the two --
-// exactly two addends per sample, in a fixed order -- and finalises those 3 / 8 of the samples.  The 134 MB frame workspace of the
-// three-kernel path (written, then read again by the overlap-add) is gone: 134 + 33 + 12.5 MB in the main kernel, 37 MB at the seams.
-constexpr int OW_HOP = 512, OW_COVER = 4, OW_HB = OW_COVER - 1;       // hop; frames covering a sample; head / tail blocks per group
+// ISTFT at hop = n_fft / 4 (2048 / 512, the reference's defaults; 1024 / 256) with the overlap-add INSIDE the transform kernel
+// (round 4): a workgroup's eight windowed frames never leave LDS.  Of the 8 hop + (n_fft - hop) output positions they touch, blocks
+// 3..7 (of hop samples) are complete and are finalised on the spot (window-sum-square division, n_fft / 2 trim, peak, one 16 B store
+// per lane); blocks 0..2 ("head") still miss the previous group's last three frames and blocks 8..10 ("tail") are this group's share
+// of the next group's head: the head is stored to the audio buffer as a partial sum, the tail to a small workspace (3 hop floats per
+// group), and a seam kernel adds the two -- exactly two addends per sample, in a fixed order -- and finalises those 3 / 8 of the
+// samples.  The frame workspace of the three-kernel path (134 MB at 64 x 256 frames of 2048: written, then read again by the
+// overlap-add) is gone: 134 + 33 + 12.5 MB in the main kernel, 37 MB at the seams.
+constexpr int OW_COVER = 4, OW_HB = OW_COVER - 1;            // frames covering a sample; head / tail blocks per group
 
 struct WssCtx { float sd, cd, sh, ch; float iw[4]; };
 // a thread's constants: window rotations by one sample / one hop, and the interior window-sum-square of its four positions
-// (positions 4 e + j with e = tid + 512 i: the residue mod hop does not depend on i because hop divides 2048)
+// (positions 4 e + j with e = tid + T i: the residue mod hop does not depend on i because hop divides 4 T)
 __device__ __forceinline__ WssCtx wss_ctx(int first_pos, int N, int hop) {
     WssCtx c;
     sincospif(2.0f / (float)N, &c.sd, &c.cd);
@@ -870,76 +927,46 @@ __device__ __forceinline__ float ola_finalize(float4& acc, int ip, int N, int ho
 }
 
 // partial[] layout of this path, per signal: [groups] peaks of the main kernel's finalised samples, then [groups] peaks of the seams
+template <int P>
 __global__ __launch_bounds__(WT, 4) void istft_ola_w_kernel(const pg_istft_args a, float* tails, float* partial) {
+    using W = WaveFft<P>;
     extern __shared__ __attribute__((aligned(16))) float2 wsm[];
     __shared__ float red[NW];
-    float2 (*regs)[WREG] = (float2 (*)[WREG])wsm;
-    float2* T1 = wsm + NW * WREG; float2* T2 = T1 + 1024;
-    constexpr int N = 2048, M = 1024, hop = OW_HOP;
+    float2 (*regs)[W::REG] = (float2 (*)[W::REG])wsm;
+    float2* T1 = wsm + NW * W::REG; float2* T2 = T1 + W::T1N;
+    constexpr int M = W::M, N = 2 * M, hop = N / OW_COVER;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int groups = (a.n_frames + NW - 1) / NW, total = a.n_signals * groups;
     const int len = hop * (a.n_frames - 1);
-    wave_fft_tables(T1, T2);
-    float cb, sb, sc, ss, sc2, ss2;
-    sincospif(2.0f * (float)lane / 1024.0f, &sb, &cb);
+    wave_fft_tables<P>(T1, T2);
+    float cb, sb, sc, ss, sc2 = 0.f, ss2 = 0.f;
+    sincospif(2.0f * (float)lane / (float)M, &sb, &cb);
     const float inv = 1.0f / (float)M;
     sincospif((float)(1 + (int)(threadIdx.x >> 1)) / (float)M, &ss, &sc);
-    sincospif((float)(257 + (int)(threadIdx.x >> 1)) / (float)M, &ss2, &sc2);
+    if (M > 512) sincospif((float)(257 + (int)(threadIdx.x >> 1)) / (float)M, &ss2, &sc2);
     const bool vec4 = (a.n_frames & 3) == 0 && ((a.a_bs | a.b_bs) & 3) == 0 && ((((uintptr_t)a.a) | ((uintptr_t)a.b)) & 15) == 0;
     const WssCtx wc = wss_ctx(4 * (int)threadIdx.x, N, hop);
-    const int half = threadIdx.x & 1;
     __syncthreads();
     for (GroupWalk gw = group_walk(total); gw.g < gw.end; gw.g += gw.step) {
         const int sig = gw.g / groups, grp = gw.g - sig * groups, t0 = grp * NW;
         const int nfr = min(NW, a.n_frames - t0);
-        const int n4 = nfr - 4 * half;
-        if (n4 > 0) {                                         // Z[k] = E[k] + i O[k] (see istft_frames4_kernel)
-            const float* pa = a.a + (long)sig * a.a_bs + t0 + 4 * half;
-            const float* pb = a.b + (long)sig * a.b_bs + t0 + 4 * half;
-            const bool vec = vec4 && n4 >= 4;
-#pragma unroll 1
-            for (int i = 0; i < 2; ++i) {
-                const int k = 1 + (int)(threadIdx.x >> 1) + 256 * i;
-                const float sn = i ? ss2 : ss, cs = i ? sc2 : sc;
-                float2 Xk[SF], Xm[SF];
-                istft_row(a, pa, pb, k, n4, vec, Xk);
-                istft_row(a, pa, pb, k == M - k ? M : M - k, n4, vec, Xm);   // (the self-paired threads read the Nyquist row here)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const float2 Xo = k == M - k ? Xk[f] : Xm[f];
-                    const float2 E = make_float2(0.5f * (Xk[f].x + Xo.x), 0.5f * (Xk[f].y - Xo.y));
-                    const float2 D = make_float2(0.5f * (Xk[f].x - Xo.x), 0.5f * (Xk[f].y + Xo.y));
-                    const float2 O = cmul(D, make_float2(cs, sn));
-                    regs[4 * half + f][k] = make_float2(E.x - O.y, E.y + O.x);
-                    if (k != M - k) regs[4 * half + f][M - k] = make_float2(E.x + O.y, O.x - E.y);
-                    else regs[4 * half + f][0] = make_float2(0.5f * Xm[f].x, -0.5f * Xm[f].x);      // Z[0]: X[0] = 0, X[M] real
-                }
-            }
-        }
+        istft_build_w<P>(a, regs, sig, t0, nfr, vec4, sc, ss, sc2, ss2);
         lds_barrier();
-        if (wave < nfr) {                                     // this wave's frame: inverse transform, window, back to its region as 2048 reals
-            float2 v[16];
+        if (wave < nfr) {                                     // this wave's frame: inverse transform, window, back to its region as n_fft reals
+            float2 v[P];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = regs[wave][lane + 64 * r];
+            for (int r = 0; r < P; ++r) v[r] = regs[wave][lane + 64 * r];
             wave_order();
-            wave_fft1024<-1>(v, regs[wave], T1, T2, lane);
+            wave_fft<-1>(v, regs[wave], T1, T2, lane);
             int lo = lane;
             asm volatile("" : "+v"(lo));
-            const int k1 = lo & 15, kh = lo >> 4;
             float cbo = cb, sbo = sb;
             asm volatile("" : "+v"(cbo), "+v"(sbo));
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float cq = __fmaf_rn(cbo, W8C[q], -(sbo * W8S[q])), sq = __fmaf_rn(sbo, W8C[q], cbo * W8S[q]);     // + q pi / 8
-#pragma unroll
-                for (int k3 = 0; k3 < 4; ++k3) {
-                    const float c = k3 == 0 ? cq : k3 == 1 ? -sq : k3 == 2 ? -cq : sq;                              // + k3 pi / 2
-                    const float sn = k3 == 0 ? sq : k3 == 1 ? cq : k3 == 2 ? -sq : -cq;
-                    float w0, w1;
-                    hann_pair(c, sn, w0, w1);
-                    const float2 z = v[4 * q + k3];
-                    regs[wave][k1 + 16 * (4 * q + kh) + 256 * k3] = make_float2(z.x * (inv * w0), z.y * (inv * w1));
-                }
+            for (int r = 0; r < P; ++r) {
+                float w0, w1;
+                hann_pair<P>(cbo, sbo, W::rot_out(r), w0, w1);
+                regs[wave][W::out(lo, r)] = make_float2(v[r].x * (inv * w0), v[r].y * (inv * w1));
             }
         }
         lds_barrier();
@@ -980,7 +1007,7 @@ __global__ __launch_bounds__(WT, 4) void istft_ola_w_kernel(const pg_istft_args 
 // the seams: head blocks of every group but the first = their own partial sums (in the audio buffer) + the previous group's tail
 __global__ __launch_bounds__(256) void istft_seam_kernel(const pg_istft_args a, const float* tails, float* partial) {
     __shared__ float red[4];
-    constexpr int N = 2048, hop = OW_HOP;
+    const int N = 2 * a.bins, hop = a.hop;                                   // (hop = n_fft / 4 on this path)
     const int groups = (a.n_frames + NW - 1) / NW;
     const int sig = blockIdx.y, grp = 1 + blockIdx.x;                        // grid (groups - 1, signals)
     const int len = hop * (a.n_frames - 1), t0 = grp * NW;
@@ -1003,7 +1030,6 @@ __global__ __launch_bounds__(256) void istft_seam_kernel(const pg_istft_args a, 
     __syncthreads();
     if (threadIdx.x == 0) partial[(long)sig * 2 * groups + groups + grp] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
-
 
 __global__ void frame_index_kernel(int n_samples, int n_fft, int hop, int n_frames, int* idx) {
     const long total = (long)n_frames * n_fft;
@@ -1173,7 +1199,7 @@ bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // the batched kernels hold 2 x SF frames of n_fft/2 complex points plus the twiddle table: 72 KB at n_fft = 2048
 constexpr int BATCHED_MAX_NFFT = 2048;
 size_t batched_lds(int n_fft) { return (size_t)(2 * SF * (n_fft / 2) + 3 * tw_len(n_fft / 2)) * sizeof(float2); }
-int wave_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (2 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }   // 78.3 KB of LDS: 2 per CU
+int wave_grid(int total, int per_cu = 2) { const int g = 8 * ((total + 7) / 8), cap = (per_cu * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }   // 78.3 KB of LDS (n_fft 2048): 2 per CU; 41.5 KB (1024): 3
 int batched_grid(int total) { const int g = 8 * ((total + 7) / 8), cap = (2 * pg_cu_count()) / 8 * 8; return g < cap ? g : (cap < 8 ? 8 : cap); }
 // the attribute belongs to (function, CURRENT device): set on every call (a host-side table write), so a process that drives
 // several devices is served too and nothing is cached between calls
@@ -1182,10 +1208,11 @@ hipError_t batched_lds_ready() {
     hipError_t e = hipFuncSetAttribute((const void*)stft_frames_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_frames_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_frames4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_frames_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_ola_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WAVE_LDS);
+    const int w16 = (int)wave_lds<16>();                     // (the 512-point kernels' 41.5 KB are below the default limit)
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_w_kernel<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, w16);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stft_w_kernel<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, w16);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_frames_w_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, w16);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)istft_ola_w_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, w16);
 
     return e;
 }
@@ -1203,10 +1230,16 @@ extern "C" int pg_stft(const pg_stft_args* a, void* stream) {
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     if (a->n_fft <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
-        if (a->n_fft == 2048) {        // one wave per frame (wave_fft1024), NW frames per workgroup
+        if (a->n_fft == 2048 || a->n_fft == 1024) {        // one wave per frame (wave_fft), NW frames per workgroup
             const int totw = a->n_signals * ((a->n_frames + NW - 1) / NW);
-            if (a->chunk_start) hipLaunchKernelGGL(stft_w_kernel<true>, dim3((unsigned)wave_grid(totw)), dim3(WT), WAVE_LDS, (hipStream_t)stream, *a);
-            else hipLaunchKernelGGL(stft_w_kernel<false>, dim3((unsigned)wave_grid(totw)), dim3(WT), WAVE_LDS, (hipStream_t)stream, *a);
+            hipStream_t st = (hipStream_t)stream;
+            if (a->n_fft == 2048) {
+                if (a->chunk_start) hipLaunchKernelGGL((stft_w_kernel<true, 16>), dim3((unsigned)wave_grid(totw)), dim3(WT), wave_lds<16>(), st, *a);
+                else hipLaunchKernelGGL((stft_w_kernel<false, 16>), dim3((unsigned)wave_grid(totw)), dim3(WT), wave_lds<16>(), st, *a);
+            } else {
+                if (a->chunk_start) hipLaunchKernelGGL((stft_w_kernel<true, 8>), dim3((unsigned)wave_grid(totw, 3)), dim3(WT), wave_lds<8>(), st, *a);
+                else hipLaunchKernelGGL((stft_w_kernel<false, 8>), dim3((unsigned)wave_grid(totw, 3)), dim3(WT), wave_lds<8>(), st, *a);
+            }
         }
         else if (a->chunk_start) hipLaunchKernelGGL(stft_frames_kernel<true>, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
         else hipLaunchKernelGGL(stft_frames_kernel<false>, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(a->n_fft), (hipStream_t)stream, *a);
@@ -1253,12 +1286,13 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
     if ((e = batched_lds_ready()) != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     const int len = a->hop * (a->n_frames - 1);
     int bx = (len / 4 + 255) / 256; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
-    // n_fft = 2048 at hop 512 (the reference's defaults, preproc_mdb.py:202-204) on 16 B-aligned audio: overlap-add inside the transform
+    // n_fft = 2048 at hop 512 (the reference's defaults, preproc_mdb.py:202-204) or 1024 at 256, 16 B-aligned audio: overlap-add inside the transform
     // kernel, seams fixed by a second one; the workspace holds [256 B][2 x groups peaks per signal][tails]
-    if (N == 2048 && a->hop == OW_HOP && !a->single_frame && (((uintptr_t)a->audio) & 15) == 0) {
+    if ((N == 2048 || N == 1024) && a->hop * OW_COVER == N && !a->single_frame && (((uintptr_t)a->audio) & 15) == 0) {
         const int groups = (a->n_frames + NW - 1) / NW;
-        float* tails = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));     // (2 x groups <= the overlap-add's block count: fits)
-        hipLaunchKernelGGL(istft_ola_w_kernel, dim3((unsigned)wave_grid(a->n_signals * groups)), dim3(WT), WAVE_LDS, st, *a, tails, partial);
+        float* tails = (float*)((char*)a->workspace + 256 + ola_partial_bytes(a));
+        if (N == 2048) hipLaunchKernelGGL(istft_ola_w_kernel<16>, dim3((unsigned)wave_grid(a->n_signals * groups)), dim3(WT), wave_lds<16>(), st, *a, tails, partial);
+        else hipLaunchKernelGGL(istft_ola_w_kernel<8>, dim3((unsigned)wave_grid(a->n_signals * groups, 3)), dim3(WT), wave_lds<8>(), st, *a, tails, partial);
         if (groups > 1) hipLaunchKernelGGL(istft_seam_kernel, dim3(groups - 1, a->n_signals), dim3(256), 0, st, *a, (const float*)tails, partial);
         if (a->normalize) hipLaunchKernelGGL(istft_peak_normalize_kernel, dim3(bx, a->n_signals), dim3(256), 0, st, a->audio, len, (const float*)partial, 2 * groups);
         e = hipGetLastError();
@@ -1266,7 +1300,8 @@ extern "C" int pg_istft(const pg_istft_args* a, void* stream) {
     }
     if (N <= BATCHED_MAX_NFFT && !a->single_frame) {
         const int total = a->n_signals * ((a->n_frames + SF - 1) / SF);
-        if (N == 2048) hipLaunchKernelGGL(istft_frames_w_kernel, dim3((unsigned)wave_grid(a->n_signals * ((a->n_frames + NW - 1) / NW))), dim3(WT), WAVE_LDS, st, *a, frames);
+        if (N == 2048) hipLaunchKernelGGL(istft_frames_w_kernel<16>, dim3((unsigned)wave_grid(a->n_signals * ((a->n_frames + NW - 1) / NW))), dim3(WT), wave_lds<16>(), st, *a, frames);
+        else if (N == 1024) hipLaunchKernelGGL(istft_frames_w_kernel<8>, dim3((unsigned)wave_grid(a->n_signals * ((a->n_frames + NW - 1) / NW), 3)), dim3(WT), wave_lds<8>(), st, *a, frames);
         else hipLaunchKernelGGL(istft_frames4_kernel, dim3((unsigned)batched_grid(total)), dim3(BT), batched_lds(N), st, *a, frames);
     } else {
         const size_t lds = (size_t)(2 * N + N / 2) * sizeof(float2);
