@@ -82,7 +82,8 @@ enum { PG_PREC_FP32 = 0, PG_PREC_BF16 = 1, PG_PREC_BF16X3 = 2 };
  * kernels (im2col kernels); bit 3: no tall (256 x 128) raw tile; bit 4: other kernels (RCCL collectives) share the chip --
  * keep the fine stream-K split even where the tile count quantises perfectly; bits 8-11: stream-K grid = that many x the
  * resident workgroup slots (1..8; 0 = default 4; > 1 bounds the tail when other kernels such as RCCL's share the chip); bit 7: the
- * wgrad keeps the flat-K kernel; bit 13: never the one-wave-per-SIMD fp32 F / T kernels (conv_raw3.hip); bit 14: those kernels wherever they cover the problem. */
+ * wgrad keeps the flat-K kernel; bit 13: never the one-wave-per-SIMD fp32 F / T kernels (conv_raw3.hip); bit 14: those kernels wherever they cover the problem;
+ * bits 15-16: their tile order (1: row-major, 2 / 3: super-rows of 2 / 4 tile rows; 0: automatic) -- measurements only. */
 enum { PG_SCHED_AUTO = 0, PG_SCHED_TILE_PER_WG = 1, PG_SCHED_FORCE_STREAMK = 2, PG_SCHED_NO_RAW = 4, PG_SCHED_NO_TALL = 8,
        PG_SCHED_CONTENDED = 16, PG_SCHED_NO_PS = 128, PG_SCHED_NO_RAW3 = 0x2000, PG_SCHED_ALL_RAW3 = 0x4000 };
 #define PG_SCHED_OVERSUB(f) (((f) & 15) << 8)

@@ -407,7 +407,8 @@ def _random_geoms_one_wave(n, seed):
     return out
 
 
-@pytest.mark.parametrize("sched", [0, 0x4000 | 2], ids=["auto", "one-wave-everywhere/stream-k"])
+@pytest.mark.parametrize("sched", [0, 0x4000 | 2, 0x4000 | (3 << 15), 0x4000 | (2 << 15) | 2, (1 << 15) | 1],
+                         ids=["auto", "one-wave-everywhere/stream-k", "super-rows-of-4", "super-rows-of-2/stream-k", "row-major/tile-per-wg"])
 @pytest.mark.parametrize("geom", _random_geoms_one_wave(32, 20261005), ids=lambda g: f"{'T' if g[0] else 'C'}{g[1]}-{g[2]}-k{g[3]}s{g[4]}p{g[5]}-L{g[6]}-B{g[7]}")
 def test_conv_random_geometries_one_wave_kernels(geom, sched):
     """forward / dgrad / wgrad (with an input activation on the window operand and the fused dgrad epilogue) of 32 seeded random

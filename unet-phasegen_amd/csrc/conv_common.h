@@ -30,6 +30,8 @@ struct IgemmParams {
     float* ws;                       // stream-K partial-tile workspace: [grid][2][64][256] floats (or NULL)
     int nslab;                       // K slabs per tile
     int whole;                       // workgroups that own one whole tile each (hybrid split; 0 = even split)
+    int sr;                          // tile order (conv_raw3): 0 / 1 = row-major; R > 1: column-major inside super-rows of R tile rows, so
+                                     // that the 32 workgroups an XCD runs at a time cover R x 32/R tiles and share activation panels too
     // bf16-resident forward kernels (conv_h3.hip): x and w are bf16; rows of x are x_pitch elements apart (even, zero tail);
     // optional bf16 outputs (B, M, yh_pitch) stored already activated.  All NULL / 0 for the fp32-tensor kernels.
     int x_pitch;
@@ -304,6 +306,13 @@ __device__ __host__ __forceinline__ int split_owner(const Split& sp, int x) {
     if (x < sp.wn) return x / sp.nslab;
     const int xr = x - sp.wn, big = sp.r * (sp.q + 1);
     return sp.w + (xr < big ? xr / (sp.q + 1) : sp.r + (xr - big) / sp.q);
+}
+// linear tile index -> (tile row, tile column)
+__device__ __forceinline__ void tile_decode(const IgemmParams& p, int tile, int& tm, int& tn) {
+    if (p.sr <= 1) { tm = tile / p.tilesN; tn = tile - tm * p.tilesN; return; }
+    const int per = p.sr * p.tilesN, s = tile / per, r = tile - s * per;
+    const int h = min(p.sr, p.tilesM - s * p.sr);             // (the last super-row may be shorter)
+    tn = r / h; tm = s * p.sr + (r - tn * h);
 }
 // hardware workgroup id -> logical id: whole-tile workgroups come first in dispatch order (they are the long ones), each class is
 // remapped so that every XCD gets a contiguous run of tiles / of remainder ranges

@@ -98,12 +98,13 @@ struct Knobs {
     int no_ps;        // wgrad: 1 = never the per-sample-slab kernel (A/B, tests)
     int no_raw3;      // 1 = never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip; schedule bit 13: A/B, tests of the older kernels)
     int all_raw3;     // 1 = the one-wave-per-SIMD kernels wherever they cover the problem (bit 14), also where auto prefers the older ones
+    int sr;           // conv_raw3 tile order: super-row height forced by schedule bits 15-16 (0 = default)
     char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
 };
 int decode_knobs(const pg_conv_args* a, Knobs& k) {
     if (a->precision < 0 || a->precision > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv: precision must be PG_PREC_FP32, PG_PREC_BF16 or PG_PREC_BF16X3");
     const int sc = a->schedule;
-    if (sc < 0 || (sc & ~0x7fff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
+    if (sc < 0 || (sc & ~0x1ffff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
     k.prec = a->precision;
     k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
     k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
@@ -114,6 +115,7 @@ int decode_knobs(const pg_conv_args* a, Knobs& k) {
     k.no_ps = (sc >> 7) & 1;
     k.no_raw3 = (sc >> 13) & 1;
     k.all_raw3 = (sc >> 14) & 1;
+    k.sr = ((sc >> 15) & 3) ? 1 << (((sc >> 15) & 3) - 1) : 0;      // bits 15-16: 1 -> R = 1 (row-major), 2 -> 2, 3 -> 4; 0 = default
     if (k.no_raw3 && k.all_raw3) return pg_fail(PG_ERR_SHAPE, "conv: schedule bits 13 and 14 exclude each other");
     k.desc = nullptr; k.desc_len = 0;
     return PG_OK;
@@ -217,6 +219,14 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     }
     if (k5 && kind != KIND_G) Ktot = (long)p.Q * (kind == KIND_T ? 4 : 8);   // F / T: K runs over the virtual taps
     p.tn_stride = bn;
+    // conv_raw3's tile order: the 32 workgroups of an XCD (256 CUs / 8) run consecutive tiles.  Row-major (R = 1) they are one tile
+    // row: they share the weight panel but each reads its own activation panel.  In super-rows of R tile rows an XCD covers R x 32/R
+    // tiles and an activation panel serves R rows at once.  Measured (tools/dbg/sr_ab.py, FETCH_SIZE per launch at the bench shape,
+    // R = 1 / 2 / 4): k = 8 layers 1.85 / 1.57 / 1.77, 1.49 / 1.22 / 1.51, 0.68 / 0.54 / 0.68 GB -- R = 2 saves 15-20 % of the L2
+    // fills; k = 32: 5.41 / 5.47 / 7.41 and 3.24 / 3.23 / 4.84 GB -- nothing at R = 2, + 40 % at R = 4: those fills are weight-panel
+    // re-reads of workgroups that drift apart over 4096 slabs, and fewer sharers per panel make it worse.  Time: equal to 0.3 %.
+    // Hence R = 2 for k = 8, row-major otherwise (schedule bits 15-16 force R = 1 / 2 / 4 for the A/B).
+    p.sr = r3 ? (kn.sr ? kn.sr : (p.k == 8 ? 2 : 1)) : 0;
     p.tilesM = (int)((rows + bm - 1) / bm);
     p.tilesN = (int)((cols + bn - 1) / bn);
     p.nslab = (int)((Ktot + BK - 1) / BK);

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(NT3, 1) void conv_raw3_kernel(const IgemmParams p) 
     while (pos < pos_end) {
         const int tile = pos / p.nslab, sb = pos - tile * p.nslab;
         const int se = min(p.nslab, sb + (pos_end - pos));
-        const int m0 = (tile / p.tilesN) * TM, n0 = (tile % p.tilesN) * TN;
+        int tmi, tni;
+        tile_decode(p, tile, tmi, tni);
+        const int m0 = tmi * TM, n0 = tni * TN;
         const int b0 = n0 / Lcol, t0 = n0 - b0 * Lcol;
         const int nseg = (t0 + TN - 1) / Lcol + 1;
 
@@ -408,7 +410,9 @@ __global__ __launch_bounds__(NT3) void conv_raw3_fixup_kernel(const IgemmParams 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc.c[0][0][r] += src[(blk * 16 + r) * NT3];
     }
-    const int mt = (tile / p.tilesN) * R3_TM, n0 = (tile % p.tilesN) * p.tn_stride + (wv * NB + bj) * 32;
+    int tmi, tni;
+    tile_decode(p, tile, tmi, tni);
+    const int mt = tmi * R3_TM, n0 = tni * p.tn_stride + (wv * NB + bj) * 32;
     if (KIND == 0) epilogue_f<0, 1, 1>(p, acc, mt + bi * 32, n0, lane, 0, 0);
     else if (KIND == 1) epilogue_t<0, 1, 1>(p, acc, mt + bi * 32, n0, lane, 0, 0);
     else epilogue_t_pm<1, 1>(p, acc, mt / 2 + (bi >> 1) * 32, n0, lane, bi & 1);

@@ -210,8 +210,9 @@ def set_conv_schedule(mode):
     split; bit 2 (value 4): im2col kernels instead of the raw-window ones; bit 3 (value 8): never the tall 256 x 128 raw tile;
     bit 7 (value 128): the wgrad keeps the flat-K raw kernel where it would take the per-sample-slab one; bit 13 (value 0x2000):
     never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip), i.e. the two-waves-per-SIMD raw kernels everywhere; bit 14 (0x4000):
-    those kernels wherever they cover the problem, also where the automatic choice keeps the older ones (F form of k = 32)."""
-    if mode < 0 or (mode & ~0x60ff) or (mode & 3) == 3 or (mode & 0x70) or (mode & 0x6000) == 0x6000:
+    those kernels wherever they cover the problem, also where the automatic choice keeps the older ones (F form of k = 32); bits 15-16:
+    their tile order (1 << 15: row-major, 2 << 15 / 3 << 15: super-rows of 2 / 4 tile rows)."""
+    if mode < 0 or (mode & ~0x1e0ff) or (mode & 3) == 3 or (mode & 0x70) or (mode & 0x6000) == 0x6000:
         raise ValueError("conv schedule: bad mode")
     _tls.schedule = (_tls.schedule & 0xf00) | mode
 
