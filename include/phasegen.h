@@ -83,9 +83,12 @@ enum { PG_PREC_FP32 = 0, PG_PREC_BF16 = 1, PG_PREC_BF16X3 = 2 };
  * keep the fine stream-K split even where the tile count quantises perfectly; bits 8-11: stream-K grid = that many x the
  * resident workgroup slots (1..8; 0 = default 4; > 1 bounds the tail when other kernels such as RCCL's share the chip); bit 7: the
  * wgrad keeps the flat-K kernel; bit 13: never the one-wave-per-SIMD fp32 F / T kernels (conv_raw3.hip); bit 14: those kernels wherever they cover the problem;
- * bits 15-16: their tile order (1: row-major, 2 / 3: super-rows of 2 / 4 tile rows; 0: automatic) -- measurements only. */
+ * bits 15-16: their tile order (1: row-major, 2 / 3: super-rows of 2 / 4 tile rows; 0: automatic) -- measurements only.
+ * PG_SCHED_NO_COLSPLIT (bit 17): the conv_raw3 launches keep a short column tail (<= 128 columns past the last full 256-wide tile)
+ * instead of handing it to a second launch of the tall-tile kernel (pg_conv_describe shows the second launch as |tail=...);
+ * PG_SCHED_COLSPLIT (bit 18): the tail launch wherever the geometry allows, whatever the cost model says (tests). */
 enum { PG_SCHED_AUTO = 0, PG_SCHED_TILE_PER_WG = 1, PG_SCHED_FORCE_STREAMK = 2, PG_SCHED_NO_RAW = 4, PG_SCHED_NO_TALL = 8,
-       PG_SCHED_CONTENDED = 16, PG_SCHED_NO_PS = 128, PG_SCHED_NO_RAW3 = 0x2000, PG_SCHED_ALL_RAW3 = 0x4000 };
+       PG_SCHED_CONTENDED = 16, PG_SCHED_NO_PS = 128, PG_SCHED_NO_RAW3 = 0x2000, PG_SCHED_ALL_RAW3 = 0x4000, PG_SCHED_NO_COLSPLIT = 0x20000, PG_SCHED_COLSPLIT = 0x40000 };
 #define PG_SCHED_OVERSUB(f) (((f) & 15) << 8)
 
 /* nn.Conv1d forward / backward (model.py:77-78; autograd of train.py:61) */
@@ -97,7 +100,7 @@ int pg_convt1d_fwd(const pg_conv_args* a, void* stream);
 int pg_convt1d_dgrad(const pg_conv_args* a, void* stream);
 int pg_convt1d_wgrad(const pg_conv_args* a, void* stream);
 /* The launch plan of one of the six calls above WITHOUT launching it (measurement aid; pure function of the arguments):
- * buf receives "kernel<template args>|grid=G|tiles=T|slabs=S|split=0/1", the kernel named as rocprofv3 reports it. */
+ * buf receives "kernel<template args>|grid=G|tiles=T|slabs=S|split=0/1|whole=W|fixup=none/plain/wide", the kernel named as rocprofv3 reports it. */
 enum { PG_OP_CONV1D_FWD = 0, PG_OP_CONV1D_DGRAD = 1, PG_OP_CONV1D_WGRAD = 2,
        PG_OP_CONVT1D_FWD = 3, PG_OP_CONVT1D_DGRAD = 4, PG_OP_CONVT1D_WGRAD = 5 };
 int pg_conv_describe(const pg_conv_args* a, int32_t op, char* buf, int32_t buflen);

@@ -97,9 +97,13 @@ def test_per_call_knobs_are_validated_and_steer_the_launch_plan():
     assert "grid=1024" in dc and "split=1" in dc                       # data-parallel backward: keep the fine split
     dw = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_WGRAD)
     assert "grid=2048|tiles=8192" in dw and "split=0" in dw            # 4 whole tiles per workgroup: no fixup either
-    dd = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_DGRAD)       # 528 tiles = 2 x 256 whole + 16 split over 256 more
+    # 64 x 65 = 4160 columns = 16 full 256-wide tiles + 64: the tail goes to a second launch of the tall-tile kernel (0.4), the 512 full
+    # tiles run two whole tiles per CU; without the tail launch 528 tiles = 2 x 256 whole + 16 split over 256 more
+    dd = ops.conv_describe(_u0_args(lib), _lib.OP_CONVT1D_DGRAD)
+    assert dd.startswith("conv_raw3_kernel<32, 2, false, false>|grid=512|tiles=512|") and "split=0" in dd and dd.endswith("|tail=conv_raw_kernel<32, 2, false, 0, 1>,grid=512")
+    dd = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_NO_COLSPLIT), _lib.OP_CONVT1D_DGRAD)
     assert dd.startswith("conv_raw3_kernel<32, 2, false, false>|") and "grid=768|tiles=528" in dd and "split=1" in dd and "whole=512" in dd
-    assert "whole=0" in ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_CONTENDED), _lib.OP_CONVT1D_DGRAD)
+    assert "whole=0" in ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_CONTENDED | _lib.SCHED_NO_COLSPLIT), _lib.OP_CONVT1D_DGRAD)
     # bit 13: the two-waves-per-SIMD raw kernels (128 x 256 tiles, two workgroups per CU) as before round 3
     d2 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_NO_RAW3), _lib.OP_CONVT1D_FWD)
     assert d2.startswith("conv_raw_kernel<32, 2, true, 0, 2>|") and "grid=1024|tiles=1024" in d2 and "split=0" in d2
@@ -110,8 +114,8 @@ def test_per_call_knobs_are_validated_and_steer_the_launch_plan():
     assert ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_NO_RAW), _lib.OP_CONVT1D_DGRAD).startswith("conv_f_kernel<0, 0, 0>|")
     one = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_TILE_PER_WG), _lib.OP_CONVT1D_FWD)
     assert "split=0" in one and "grid=512|tiles=512" in one
-    g4 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_FORCE_STREAMK), _lib.OP_CONVT1D_DGRAD)
-    g1 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_FORCE_STREAMK | (1 << 8)), _lib.OP_CONVT1D_DGRAD)   # oversubscribe factor 1
+    g4 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_FORCE_STREAMK | _lib.SCHED_NO_COLSPLIT), _lib.OP_CONVT1D_DGRAD)
+    g1 = ops.conv_describe(_u0_args(lib, schedule=_lib.SCHED_FORCE_STREAMK | _lib.SCHED_NO_COLSPLIT | (1 << 8)), _lib.OP_CONVT1D_DGRAD)   # oversubscribe factor 1
     assert "grid=1024" in g4 and "grid=256" in g1
     buf = ctypes.create_string_buffer(256)
     assert lib.pg_conv_describe(ctypes.byref(_u0_args(lib, precision=3)), 3, buf, 256) == -4      # PG_ERR_UNSUPPORTED

@@ -31,6 +31,8 @@ GEOMS = [
     (True, 264, 132, 8, 2, 1, 29, 2), (True, 264, 132, 8, 1, 2, 62, 2), (True, 200, 140, 32, 2, 16, 65, 2),
     (False, 64, 128, 32, 2, 16, 256, 5), (True, 128, 64, 32, 2, 16, 129, 5), (True, 64, 96, 8, 1, 2, 126, 6), (False, 64, 96, 8, 2, 1, 126, 6),
     (True, 32, 16, 5, 2, 1, 1, 2), (True, 264, 130, 5, 2, 1, 14, 3), (True, 128, 96, 5, 2, 1, 30, 9),      # k = 5: shadow padded to 4 taps per phase
+    # few columns, long K (a single clip): one or two tiles in tens to hundreds of segments -> the wide fixup of conv_h3.hip
+    (False, 512, 250, 32, 2, 16, 24, 1), (True, 768, 120, 8, 1, 2, 20, 1), (True, 1024, 300, 8, 2, 1, 14, 2), (False, 608, 300, 4, 2, 1, 30, 1),
 ]
 
 

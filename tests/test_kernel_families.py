@@ -98,3 +98,49 @@ def test_the_resident_forward_has_one_family():
     a.schedule = 64
     buf = ctypes.create_string_buffer(256)
     assert _lib.load().pg_conv_fwd_h_describe(ctypes.byref(a), buf, 256) == _lib.ERR_UNSUPPORTED
+
+
+def test_fixup_form_follows_segments_per_split_tile():
+    """The wide fixup (four workgroups per 32 x 32 block, segments summed four abreast) is taken from 8 segments per split tile on --
+    demo.py's single clip: 8-16 tiles over 512 workgroups -- and never at the bench shapes (2-3 segments per split tile): the order in
+    which a tile's segments are added is a function of (grid, tiles) alone."""
+    from phasegen import _lib, ops
+
+    def fields(d):
+        return dict(kv.split("=", 1) for kv in d.split("|")[1:])
+
+    for name, tr, Cin, Cout, k, s, p, Lin in layers(1024, 128):
+        f = fields(ops.conv_describe(_args(_lib, 1, Cin, Cout, Lin, k, s, p, tr), _lib.OP_CONVT1D_FWD if tr else _lib.OP_CONV1D_FWD))
+        assert f["split"] == "1" and f["fixup"] == "wide" and int(f["grid"]) >= 8 * (int(f["tiles"]) - int(f["whole"])), (name, f)
+    seen = set()
+    for name, tr, Cin, Cout, k, s, p, Lin in layers(1024, 256):
+        for op in ((_lib.OP_CONVT1D_FWD, _lib.OP_CONVT1D_DGRAD, _lib.OP_CONVT1D_WGRAD) if tr else (_lib.OP_CONV1D_FWD, _lib.OP_CONV1D_WGRAD)):
+            f = fields(ops.conv_describe(_args(_lib, 64, Cin, Cout, Lin, k, s, p, tr), op))
+            seen.add(f["fixup"])
+    assert seen <= {"none", "plain"}, seen
+
+
+def test_column_tail_launch_policy():
+    """A conv_raw3 problem whose columns end <= 128 past a full 256-wide tile hands that tail to a second launch of the tall-tile
+    kernel where the cost model prices the tail under the extra tile column: the bench shape's 64 x 129 = 8256 and 64 x 61 = 3904
+    columns on the long-K layers, the reference's own 16 x 65 = 1040; never where the tail is half a tile (64 x 126 = 8064, 64 x 30),
+    never under one-tile-per-workgroup, and PG_SCHED_NO_COLSPLIT turns it off."""
+    from phasegen import _lib, ops
+    plan = {}
+    for name, tr, Cin, Cout, k, s, p, Lin in layers(1024, 256):
+        for opn, op in (("fwd", _lib.OP_CONVT1D_FWD if tr else _lib.OP_CONV1D_FWD), ("dgrad", _lib.OP_CONVT1D_DGRAD if tr else _lib.OP_CONV1D_DGRAD)):
+            if (name, opn) != ("D0", "dgrad"):
+                plan[name + "." + opn] = ops.conv_describe(_args(_lib, 64, Cin, Cout, Lin, k, s, p, tr), op)
+    tails = sorted(n for n, d in plan.items() if "|tail=" in d)
+    assert tails == ["D0.fwd", "D1.dgrad", "D2.fwd", "U0.dgrad", "U1.fwd", "U2.dgrad"], tails
+    for n in tails:
+        assert plan[n].startswith("conv_raw3_kernel<") and "|tail=conv_raw_kernel<" in plan[n] and ", 0, 1>,grid=" in plan[n].split("|tail=")[1], plan[n]
+    assert "|split=0|" in plan["D0.fwd"] and "|split=0|" in plan["U0.dgrad"]      # 256 / 512 full tiles: whole tiles per workgroup, no fixup
+    d0 = ("D0", False, 1024, 2048, 32, 2, 16, 256)
+    for sched in (_lib.SCHED_NO_COLSPLIT, _lib.SCHED_TILE_PER_WG, _lib.SCHED_NO_TALL):
+        assert "|tail=" not in ops.conv_describe(_args(_lib, 64, *d0[2:4], d0[7], *d0[4:7], False, schedule=sched), _lib.OP_CONV1D_FWD), sched
+    ref = ops.conv_describe(_args(_lib, 16, 1024, 2048, 128, 32, 2, 16, False), _lib.OP_CONV1D_FWD)
+    assert ref.startswith("conv_raw3_kernel<32, 2, false, false>|grid=256|tiles=32|") and "|tail=conv_raw_kernel<32, 2, false, 0, 1>" in ref, ref
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(256)
+    assert lib.pg_conv_describe(ctypes.byref(_args(_lib, 64, 1024, 2048, 256, 32, 2, 16, False, schedule=0x60000)), _lib.OP_CONV1D_FWD, buf, 256) == -2

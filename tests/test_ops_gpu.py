@@ -55,20 +55,27 @@ GEOMS = [
     # k = 5 at stride 2 on the one-wave-per-SIMD kernels (a virtual k = 8 whose virtual taps' MFMAs are never issued): forward and dgrad
     # of both layer kinds with ~250 GEMM rows on the side that takes them
     (True, 48, 125, 5, 2, 1, 30, 6), (False, 32, 250, 5, 2, 2, 61, 4), (False, 125, 40, 5, 2, 2, 61, 4), (True, 250, 40, 5, 2, 1, 30, 5),
+    # few columns, long K (a single clip through wide layers): one or two tiles split into tens to hundreds of segments -- the wide
+    # fixup (conv_igemm.hip, fixup_wide) in every form: F, T stride 1, T stride 2 (phase-major rows), and a wgrad over 18 000 frames
+    (False, 512, 250, 32, 2, 16, 24, 1), (True, 768, 120, 8, 1, 2, 20, 1), (True, 1024, 120, 8, 2, 1, 14, 2), (True, 640, 130, 32, 2, 16, 9, 1),
+    (False, 600, 300, 4, 2, 1, 30, 1), (False, 8, 16, 8, 1, 2, 3000, 6),
 ]
 
 
-@pytest.fixture(params=[1, 2, 5, 6, 10, 128 | 2, 0x2000 | 1, 0x2000 | 2, 0x4000 | 1, 0x4000 | 2],
+@pytest.fixture(params=[1, 2, 5, 6, 10, 128 | 2, 0x2000 | 1, 0x2000 | 2, 0x4000 | 1, 0x4000 | 2, 0x40000, 0x40000 | 0x4000 | 2],
                 ids=["raw/tile-per-wg", "raw/stream-k", "im2col/tile-per-wg", "im2col/stream-k", "raw-wide-only/stream-k",
                      "flat-K-wgrad/stream-k", "raw-2-waves-per-simd/tile-per-wg", "raw-2-waves-per-simd/stream-k",
-                     "raw-1-wave-per-simd-everywhere/tile-per-wg", "raw-1-wave-per-simd-everywhere/stream-k"])
+                     "raw-1-wave-per-simd-everywhere/tile-per-wg", "raw-1-wave-per-simd-everywhere/stream-k",
+                     "column-tail-launch/auto", "column-tail-launch/1-wave-everywhere/stream-k"])
 def schedule(request):
     """Run the conv tests under both work decompositions (one whole tile per workgroup; the persistent stream-K split
     with partial tiles through the workspace + fixup kernel, which the library otherwise only picks for tile counts
     that quantise badly over the CUs) and with the raw-window F/T kernels enabled or disabled (bit 2), so the im2col
     kernels they normally replace stay covered; bit 3 keeps the small problems of this file on the wide 128 x 256 raw tile
     (they otherwise take the tall 256 x 128 one), so both tile shapes see every geometry; bit 7 keeps the wgrad on the flat-K kernel
-    where it would take the per-sample-slab one; bit 13 keeps the fp32 F / T problems that conv_raw3.hip covers on the older
+    where it would take the per-sample-slab one; bit 18 hands the columns past the last full 256-wide tile of a conv_raw3 problem to a
+    second launch of the tall-tile kernel wherever the geometry allows (the automatic choice does so only where its cost model says the
+    tail is cheaper than another tile column -- never on problems of this file's size); bit 13 keeps the fp32 F / T problems that conv_raw3.hip covers on the older
     two-waves-per-SIMD raw kernels, bit 14 puts every problem they cover on them (the F form of k = 32 is otherwise left out)."""
     from phasegen import ops
     ops.set_conv_schedule(request.param)
@@ -407,8 +414,9 @@ def _random_geoms_one_wave(n, seed):
     return out
 
 
-@pytest.mark.parametrize("sched", [0, 0x4000 | 2, 0x4000 | (3 << 15), 0x4000 | (2 << 15) | 2, (1 << 15) | 1],
-                         ids=["auto", "one-wave-everywhere/stream-k", "super-rows-of-4", "super-rows-of-2/stream-k", "row-major/tile-per-wg"])
+@pytest.mark.parametrize("sched", [0, 0x4000 | 2, 0x4000 | (3 << 15), 0x4000 | (2 << 15) | 2, (1 << 15) | 1, 0x40000 | 0x4000, 0x40000 | 2],
+                         ids=["auto", "one-wave-everywhere/stream-k", "super-rows-of-4", "super-rows-of-2/stream-k", "row-major/tile-per-wg",
+                              "column-tail-launch/one-wave-everywhere", "column-tail-launch/stream-k"])
 @pytest.mark.parametrize("geom", _random_geoms_one_wave(32, 20261005), ids=lambda g: f"{'T' if g[0] else 'C'}{g[1]}-{g[2]}-k{g[3]}s{g[4]}p{g[5]}-L{g[6]}-B{g[7]}")
 def test_conv_random_geometries_one_wave_kernels(geom, sched):
     """forward / dgrad / wgrad (with an input activation on the window operand and the fused dgrad epilogue) of 32 seeded random
@@ -479,7 +487,9 @@ def _bn_cases():
     # (B, C, L, channel offset of the views inside wider buffers, extra channels of those buffers)
     return [(64, 24, 256, 0, 0), (64, 16, 256, 8, 16), (64, 16, 126, 0, 0), (64, 16, 126, 3, 5), (64, 12, 129, 0, 0), (64, 12, 61, 1, 2),
             (7, 20, 128, 0, 4), (5, 9, 4, 0, 0), (3, 7, 2, 2, 2), (1, 6, 1000, 0, 0), (16, 8, 1024, 0, 0), (2, 5, 8192, 0, 0), (3, 4, 6000, 0, 0),
-            (1, 3, 2, 0, 0), (33, 10, 30, 5, 0)]
+            (1, 3, 2, 0, 0), (33, 10, 30, 5, 0),
+            # single clips (demo.py): one or two units per thread -- the smallest instantiation of each unit width
+            (1, 10, 64, 0, 0), (1, 6, 66, 0, 0), (1, 6, 66, 1, 0), (2, 5, 65, 0, 0), (1, 7, 130, 1, 0), (3, 5, 128, 0, 4)]
 
 
 @pytest.mark.parametrize("case", _bn_cases(), ids=lambda c: "B%d-C%d-L%d-off%d+%d" % c)

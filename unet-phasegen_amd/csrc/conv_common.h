@@ -31,6 +31,7 @@ struct IgemmParams {
     int nslab;                       // K slabs per tile
     int whole;                       // workgroups that own one whole tile each (hybrid split; 0 = even split)
     int sr;                          // tile order (conv_raw3): 0 / 1 = row-major; R > 1: column-major inside super-rows of R tile rows, so
+    int n_lo;                        // first column of this launch (0 but for the tail launch of a column split, conv_igemm.hip launch())
                                      // that the 32 workgroups an XCD runs at a time cover R x 32/R tiles and share activation panels too
     // bf16-resident forward kernels (conv_h3.hip): x and w are bf16; rows of x are x_pitch elements apart (even, zero tail);
     // optional bf16 outputs (B, M, yh_pitch) stored already activated.  All NULL / 0 for the fp32-tensor kernels.
@@ -534,7 +535,7 @@ hipError_t launch_raw_ft_tall(int kind, const IgemmParams& p, int grid, hipStrea
 hipError_t launch_raw_g(const IgemmParams& p, int grid, hipStream_t st, int prec);              // conv_raw_wgrad.hip
 // conv_h3.hip: 4 waves at ONE per SIMD, wave tile 256 x 64, tile 256 x 256
 hipError_t launch_h3(int kind, const IgemmParams& p, int grid, hipStream_t st);
-hipError_t launch_h3_fixup(int kind, const IgemmParams& p, int grid, unsigned blocks, hipStream_t st);
+hipError_t launch_h3_fixup(int kind, const IgemmParams& p, int grid, unsigned split_tiles, bool wide, hipStream_t st);
 // conv_raw3.hip: fp32 raw-window F / T kernels on 4 waves at ONE per SIMD, tile 256 x 256
 bool raw3_covers(int kind, const IgemmParams& p);               // (k, s) pair and whole-slab K; the window-length bound is raw_supported's
 hipError_t launch_raw3(int kind, const IgemmParams& p, int grid, hipStream_t st);

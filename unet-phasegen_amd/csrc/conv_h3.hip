@@ -343,13 +343,18 @@ __global__ __launch_bounds__(NT3, 1) void conv_h3_kernel(const IgemmParams p) {
     }
 }
 
-// fixup of the stream-K split: one workgroup per (split tile, 32 x 32 block index of the wave tile: 16 of them)
-template <int KIND>
+// fixup of the stream-K split: one workgroup per (split tile, 32 x 32 block index of the wave tile: 16 of them); WIDE (many
+// segments per tile, small-batch inference): four workgroups per block, one per GEMM wave, whose four waves each sum every fourth
+// segment and wave 0 adds the four sums in order (conv_igemm.hip's conv_fixup_kernel has the same two forms)
+template <int KIND, bool WIDE>
 __global__ __launch_bounds__(NT3) void conv_h3_fixup_kernel(const IgemmParams p, int G) {
     constexpr int MB = 8, NB = 2;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ float red[WIDE ? 3 * 16 * 64 : 1];
+    const int unit = WIDE ? blockIdx.x >> 2 : blockIdx.x, q = WIDE ? threadIdx.x >> 6 : 0;
+    const int tid = WIDE ? (blockIdx.x & 3) * 64 + (threadIdx.x & 63) : threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const int wm = 0, wn = wv;
-    const int tile = p.whole + blockIdx.x / (MB * NB), blk = blockIdx.x % (MB * NB), bi = blk / NB, bj = blk - bi * NB;
+    const int tile = p.whole + unit / (MB * NB), blk = unit % (MB * NB), bi = blk / NB, bj = blk - bi * NB;
     const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, G, p.whole);
     const int first = tile * p.nslab, last = first + p.nslab - 1;
     const int g0 = split_owner(sp, first), g1 = split_owner(sp, last);
@@ -358,11 +363,24 @@ __global__ __launch_bounds__(NT3) void conv_h3_fixup_kernel(const IgemmParams p,
     AccT<1, 1> acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc.c[0][0][r] = 0.f;
-    for (int g = g0; g <= g1; ++g) {
+#pragma unroll 2
+    for (int g = g0 + q; g <= g1; g += WIDE ? 4 : 1) {
         const int slot = (split_lo(sp, g) / p.nslab == tile) ? 0 : 1;
         const float* src = p.ws + ((long)(g * 2 + slot) * H3_REGS) * NT3 + tid;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc.c[0][0][r] += src[(blk * 16 + r) * NT3];
+    }
+    if (WIDE) {         // (the returns above are uniform over the workgroup here)
+        if (q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((q - 1) * 16 + r) * 64 + lane] = acc.c[0][0][r];
+        }
+        __syncthreads();
+        if (q) return;
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.c[0][0][r] += red[(qq * 16 + r) * 64 + lane];
     }
     const int m0 = (tile / p.tilesN) * 256 + wm * (MB - 1) * 32 + bi * 32;
     const int n0 = (tile % p.tilesN) * p.tn_stride + wn * (NB - 1) * 32 + bj * 32;
@@ -429,8 +447,11 @@ hipError_t pgconv::launch_h3(int kind, const IgemmParams& p, int grid, hipStream
     return launch3<8, 2, true>(p, grid, st);
 }
 
-hipError_t pgconv::launch_h3_fixup(int kind, const IgemmParams& p, int grid, unsigned blocks, hipStream_t st) {
-    if (kind == KIND_F) hipLaunchKernelGGL((conv_h3_fixup_kernel<0>), dim3(blocks), dim3(NT3), 0, st, p, grid);
-    else hipLaunchKernelGGL((conv_h3_fixup_kernel<1>), dim3(blocks), dim3(NT3), 0, st, p, grid);
+hipError_t pgconv::launch_h3_fixup(int kind, const IgemmParams& p, int grid, unsigned split_tiles, bool wide, hipStream_t st) {
+    const dim3 fg(split_tiles * (wide ? 64 : 16));
+    if (kind == KIND_F) { if (wide) hipLaunchKernelGGL((conv_h3_fixup_kernel<0, true>), fg, dim3(NT3), 0, st, p, grid);
+                          else hipLaunchKernelGGL((conv_h3_fixup_kernel<0, false>), fg, dim3(NT3), 0, st, p, grid); }
+    else { if (wide) hipLaunchKernelGGL((conv_h3_fixup_kernel<1, true>), fg, dim3(NT3), 0, st, p, grid);
+           else hipLaunchKernelGGL((conv_h3_fixup_kernel<1, false>), fg, dim3(NT3), 0, st, p, grid); }
     return hipGetLastError();
 }

@@ -35,6 +35,8 @@
 // LDS.  Work decomposition is a persistent stream-K split over (tile, slab) with a deterministic fixup kernel (below).
 // Each output element is accumulated in a fixed order: results are bit-reproducible.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <cmath>
 #include "conv_common.h"
 
 namespace {
@@ -43,34 +45,53 @@ namespace {
 // One workgroup per (tile, 32 x 32 block of the wave tile): with few tiles and many segments (small-batch inference: 8 tiles
 // split over 512 workgroups) one workgroup per tile would read 8 MB on its own; per block the reduction is MB*NB times wider.
 // WN = waves of the GEMM kernel along N (2: tile 64 MB x 64 NB; 1: the raw "tall" tile 128 MB x 32 NB).
-template <int KIND, int MB, int NB, int WN = 2>
+// WIDE (small-batch inference: tens of segments per tile): four workgroups per block, one per wave of the GEMM kernel; the four
+// waves of a fixup workgroup each sum every fourth segment (two segments' loads in flight per wave) and wave 0 adds the four
+// sums in order -- a fixed order, chosen by the host from (grid, tiles) alone.  8 tiles x 64 segments: 36 us -> see DESIGN 4.3.
+template <int KIND, int MB, int NB, int WN = 2, bool WIDE = false>
 __global__ __launch_bounds__(NT) void conv_fixup_kernel(const IgemmParams p, int G) {
     // WN = waves of the GEMM kernel along N: 2 -> 2 x 2 waves, 1 -> 4 x 1 (tall raw tile), 4 -> 1 x 4 (bf16-resident kernels)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ float red[WIDE ? 3 * 16 * 64 : 1];
+    const int unit = WIDE ? blockIdx.x >> 2 : blockIdx.x, q = WIDE ? threadIdx.x >> 6 : 0;
+    const int tid = WIDE ? (blockIdx.x & 3) * 64 + (threadIdx.x & 63) : threadIdx.x;     // the GEMM thread whose accumulators this lane sums
+    const int lane = tid & 63, wv = tid >> 6;
     const int wm = WN == 2 ? wv >> 1 : (WN == 4 ? 0 : wv), wn = WN == 2 ? wv & 1 : (WN == 4 ? wv : 0);
     static_assert(MB * NB * 16 == ACC_REGS, "8 blocks per wave tile: the host launches 8 workgroups per tile");
     // hybrid split: tiles below p.whole were computed whole by one workgroup each -- the grid covers the split tiles only
-    const int tile = p.whole + blockIdx.x / (MB * NB), blk = blockIdx.x % (MB * NB), bi = blk / NB, bj = blk - bi * NB;
+    const int tile = p.whole + unit / (MB * NB), blk = unit % (MB * NB), bi = blk / NB, bj = blk - bi * NB;
     const Split sp = make_split(p.tilesM * p.tilesN, p.nslab, G, p.whole);
     const int first = tile * p.nslab, last = first + p.nslab - 1;
     const int g0 = split_owner(sp, first), g1 = split_owner(sp, last);
     if (g0 == g1 && split_lo(sp, g0) <= first && split_lo(sp, g0 + 1) > last) return;   // computed whole by one workgroup
     // a 32-column block that starts past the problem's last column holds nothing (few-column problems on the tall tile: the GEMM
     // kernel did not write it either)
-    if (KIND != 2 && (tile % p.tilesN) * p.tn_stride + (WN == 2 ? wn * (NB - 1) * 32 : (WN == 4 ? wn * (NB * 32) : 0)) + bj * 32 >= p.B * (KIND == 0 ? p.Ly : p.U)) return;
+    if (KIND != 2 && p.n_lo + (tile % p.tilesN) * p.tn_stride + (WN == 2 ? wn * (NB - 1) * 32 : (WN == 4 ? wn * (NB * 32) : 0)) + bj * 32 >= p.B * (KIND == 0 ? p.Ly : p.U)) return;
     AccT<1, 1> acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc.c[0][0][r] = 0.f;
-    for (int g = g0; g <= g1; ++g) {
+#pragma unroll 2
+    for (int g = g0 + q; g <= g1; g += WIDE ? 4 : 1) {
         const int slot = (split_lo(sp, g) / p.nslab == tile) ? 0 : 1;     // the range's first segment, or its last
         const float* src = p.ws + ((long)(g * 2 + slot) * ACC_REGS) * NT + tid;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc.c[0][0][r] += src[(blk * 16 + r) * NT];
     }
+    if (WIDE) {         // (the returns above are uniform over the workgroup here: all four waves stand for the same GEMM wave)
+        if (q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((q - 1) * 16 + r) * 64 + lane] = acc.c[0][0][r];
+        }
+        __syncthreads();
+        if (q) return;
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.c[0][0][r] += red[(qq * 16 + r) * 64 + lane];
+    }
     // the epilogues place block (0, 0) of wave (wm, wn) at m0 + wm * 32, n0 + wn * 32: shift the origin to block (bi, bj)
     const int m0 = (tile / p.tilesN) * ((4 / WN) * 32 * MB) + wm * (MB - 1) * 32 + bi * 32;
     // column tiles are p.tn_stride columns apart: the tile width, except the k = 5 wgrad's 255 (51 whole channels) of 256
-    const int nt0 = (tile % p.tilesN) * p.tn_stride;
+    const int nt0 = p.n_lo + (tile % p.tilesN) * p.tn_stride;
     const int n0 = nt0 + wn * (NB - 1) * 32 + bj * 32;
     if (KIND == 0) epilogue_f<0, 1, 1>(p, acc, m0, n0, lane, wm, wn);
     else if (KIND == 3)       // stride-2 raw T kernels (phase-major rows): block row bi is phase bi of the wave's 32 output channels
@@ -99,12 +120,14 @@ struct Knobs {
     int no_raw3;      // 1 = never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip; schedule bit 13: A/B, tests of the older kernels)
     int all_raw3;     // 1 = the one-wave-per-SIMD kernels wherever they cover the problem (bit 14), also where auto prefers the older ones
     int sr;           // conv_raw3 tile order: super-row height forced by schedule bits 15-16 (0 = default)
+    int force_colsplit;   // 1 = split wherever the geometry allows, whatever the cost model says (bit 18: tests reach the tail launch on small problems)
+    int no_colsplit;  // 1 = never split the columns past the last full 256-wide tile off into a tail launch (bit 17: A/B, tests)
     char* desc; int desc_len;   // pg_conv_describe: write the launch plan here INSTEAD of launching
 };
 int decode_knobs(const pg_conv_args* a, Knobs& k) {
     if (a->precision < 0 || a->precision > 2) return pg_fail(PG_ERR_UNSUPPORTED, "conv: precision must be PG_PREC_FP32, PG_PREC_BF16 or PG_PREC_BF16X3");
     const int sc = a->schedule;
-    if (sc < 0 || (sc & ~0x1ffff) || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
+    if (sc < 0 || (sc & ~0x7ffff) || ((sc >> 17) & 3) == 3 || (sc & 3) == 3 || ((sc >> 8) & 15) > 8) return pg_fail(PG_ERR_SHAPE, "conv: bad schedule bits");
     k.prec = a->precision;
     k.force_mode = sc & 3; k.no_raw = (sc >> 2) & 1; k.no_tall = (sc >> 3) & 1;
     k.oversub = (sc >> 8) & 15; if (!k.oversub) k.oversub = 4;
@@ -116,12 +139,16 @@ int decode_knobs(const pg_conv_args* a, Knobs& k) {
     k.no_raw3 = (sc >> 13) & 1;
     k.all_raw3 = (sc >> 14) & 1;
     k.sr = ((sc >> 15) & 3) ? 1 << (((sc >> 15) & 3) - 1) : 0;      // bits 15-16: 1 -> R = 1 (row-major), 2 -> 2, 3 -> 4; 0 = default
+    k.no_colsplit = (sc >> 17) & 1;
+    k.force_colsplit = (sc >> 18) & 1;
     if (k.no_raw3 && k.all_raw3) return pg_fail(PG_ERR_SHAPE, "conv: schedule bits 13 and 14 exclude each other");
     k.desc = nullptr; k.desc_len = 0;
     return PG_OK;
 }
 
 int cu_count() { return pg_cu_count(); }
+// the wide fixup (four workgroups per 32 x 32 block, segments summed four abreast) from 8 segments per split tile on
+bool fixup_wide(int grid, long split_tiles) { return split_tiles > 0 && grid >= 8 * split_tiles; }
 
 // Grid policy.  Default: a persistent stream-K grid of up to oversub (4) x the resident workgroup slots, each
 // workgroup owning an equal contiguous range of the (tile, slab) space, plus the fixup launch.  Measured on MI355X
@@ -188,7 +215,8 @@ bool raw_supported(Kind kind, const IgemmParams& p, const Knobs& kn, int tn = RB
     return sc * (tn - 1) + tj + raw_gap(tj) * (nseg_max - 1) + (kind == KIND_T ? tj : 0) <= (sc == 1 ? RS1 : RS2);
 }
 
-int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, long Ktot, long ws_bytes, hipStream_t st) {
+int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, long Ktot, long ws_bytes, hipStream_t st, bool may_split = true) {
+    const long Ktot_in = Ktot;
     bool raw = raw_supported(kind, p, kn);
     // F / T problems whose columns the tall 256 x 128 tile covers with at least 3 % fewer computed ones take it (and those whose
     // windows only fit the narrower tile: many short samples per tile): small-batch
@@ -204,8 +232,9 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     // Over the tall tile too where 256-wide tiles compute at most 8 % more columns (D2 forward / U2 dgrad / D3 forward at batch 64:
     // -6 / -2 / -6 %, and 2.2 instead of 6.95 GB of L2 fills; batch-1 inference and N = 16 x 65 keep the tall tile).
     const bool r3_over_tall = tall && raw_supported(kind, p, kn) && (kn.all_raw3 || cols_wide * 100 <= cols_tall * 108);
-    const bool r3 = raw && (!tall || r3_over_tall) && kind != KIND_G && kn.prec == 0 && !kn.no_raw3 && pgconv::raw3_covers(kind, p) &&
-                    (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103;
+    const bool r3_ok = raw && raw_supported(kind, p, kn) && kind != KIND_G && kn.prec == 0 && !kn.no_raw3 && pgconv::raw3_covers(kind, p) &&
+                       (rows + 255) / 256 * 256 * 100 <= (rows + RBM - 1) / RBM * RBM * 103;
+    const bool r3 = r3_ok && (!tall || r3_over_tall);
     const int bm = (tall || r3) ? 2 * RBM : (raw ? RBM : BM);
     int bn = (tall && !r3) ? RBN / 2 : (raw ? RBN : BN);
     const bool k5 = raw && p.k == 5 && p.s == 2;
@@ -218,6 +247,39 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
         if ((cps * 16 - p.LP) * 100 <= 7L * p.LP && !kn.no_ps) { p.g_ps = 1; Ktot = (long)p.B * cps * 16; }
     }
     if (k5 && kind != KIND_G) Ktot = (long)p.Q * (kind == KIND_T ? 4 : 8);   // F / T: K runs over the virtual taps
+    // Column split (round 4).  conv_raw3's tiles are 256 columns wide: 64 x 129 frames are 32.25 of them, and the 33rd tile column
+    // costs what the other 32 cost each (2.3 % of D0 forward / U0 dgrad; at the reference's own batch of 16 x 65 = 1040 columns a
+    // FIFTH of five).  Where the columns past the last full tile are few (<= 128), the launch covers full tiles only and a second
+    // launch of the tall two-waves-per-SIMD kernel (256 x 128, column blocks without columns skipped) takes the tail from column
+    // n_lo on: a weight-streaming pass like demo.py's single clip (the weights once at ~3 TB/s, or its own MFMA work), taken when
+    // the model below says it costs under 1 / 1.3 of the tile column it replaces.  A pure function of the geometry.
+    if (may_split && r3_ok && kn.force_mode != 1 && !kn.no_colsplit && !kn.no_tall) {      // (r3_ok: also where the whole problem would take the tall tile)
+        const long full = cols / RBN * RBN, rem = cols - full;
+        if (full > 0 && rem > 0 && rem <= RBN / 2 && raw_supported(kind, p, kn, RBN / 2)) {
+            const double rows_p = (double)((rows + 255) / 256 * 256), rem32 = (double)((rem + 31) / 32 * 32), Kd = (double)Ktot;
+            const double t_col = 2.0 * rows_p * 256.0 * Kd / 140e6;                                              // us at 140 TFLOP/s
+            const double t_tail = fmax(4.0 * (double)rows * Kd / 3e6, 2.0 * rows_p * rem32 * Kd / 100e6) + 25.0;  // us: 3 TB/s | 100 TFLOP/s, + launches
+            if (t_col > 1.3 * t_tail || kn.force_colsplit) {
+                Knobs kb = kn;
+                kb.no_raw3 = 1; kb.all_raw3 = 0;
+                char tail[160] = "";
+                if (kn.desc) { kb.desc = tail; kb.desc_len = (int)sizeof tail; }
+                int rc = launch(kind, p, kn, rows, full, Ktot_in, ws_bytes, st, false);
+                if (rc != PG_OK) return rc;
+                IgemmParams pb = p;
+                pb.n_lo = (int)full;
+                rc = launch(kind, pb, kb, rows, rem, Ktot_in, ws_bytes, st, false);
+                if (rc == PG_OK && kn.desc) {          // "...|tail=conv_raw_kernel<...>,grid=G"
+                    char* bar = strchr(tail, '|');
+                    if (bar) { *bar = ','; bar = strchr(bar, '|'); if (bar) *bar = 0; }
+                    const size_t n = strlen(kn.desc);
+                    if (n + 7 < (size_t)kn.desc_len) snprintf(kn.desc + n, (size_t)kn.desc_len - n, "|tail=%s", tail);
+                }
+                return rc;
+            }
+        }
+    }
+    if (p.n_lo && !(tall && !r3)) return pg_fail(PG_ERR_UNSUPPORTED, "conv: internal -- a column tail off the tall tile");
     p.tn_stride = bn;
     // conv_raw3's tile order: the 32 workgroups of an XCD (256 CUs / 8) run consecutive tiles.  Row-major (R = 1) they are one tile
     // row: they share the weight panel but each reads its own activation panel.  In super-rows of R tile rows an XCD covers R x 32/R
@@ -242,7 +304,8 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
         else if (r3) snprintf(name, sizeof name, "conv_raw3_kernel<%d, %d, %s, %s>", p.k, p.s, kind == KIND_T ? "true" : "false", p.act_x == PG_ACT_NONE ? "false" : "true");
         else if (raw) snprintf(name, sizeof name, "conv_raw_kernel<%d, %d, %s, %d, %d>", p.k, p.s, kind == KIND_T ? "true" : "false", kn.prec, tall ? 1 : 2);
         else snprintf(name, sizeof name, "conv_%c_kernel<0, 0, %d>", kind == KIND_F ? 'f' : (kind == KIND_T ? 't' : 'g'), kn.prec);
-        snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d", name, grid, tiles, p.nslab, (int)split, p.whole);
+        snprintf(kn.desc, (size_t)kn.desc_len, "%s|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d|fixup=%s", name, grid, tiles, p.nslab, (int)split, p.whole,
+                 !split ? "none" : (!r3 && fixup_wide(grid, tiles - p.whole) ? "wide" : "plain"));
         return PG_OK;
     }
     hipError_t e;
@@ -253,20 +316,27 @@ int launch(Kind kind, IgemmParams& p, const Knobs& kn, long rows, long cols, lon
     else e = pgconv::launch_im2col(kind, p, grid, st, kn.prec);
     if (e == hipSuccess && split && r3) e = pgconv::launch_raw3_fixup(kind, p, grid, (unsigned)((tiles - p.whole) * 16), st);
     else if (e == hipSuccess && split) {
+        // many segments per split tile (small-batch inference) -> the wide fixup: the order in which a tile's segments are added is a
+        // function of (grid, tiles) only, so a geometry always takes the same one
+        const bool wide = fixup_wide(grid, tiles - p.whole);
+        const dim3 fg((unsigned)((tiles - p.whole) * (wide ? 32 : 8)));
+#define PG_FIXUP(...) { if (wide) hipLaunchKernelGGL((conv_fixup_kernel<__VA_ARGS__, true>), fg, dim3(NT), 0, st, p, grid); \
+                        else hipLaunchKernelGGL((conv_fixup_kernel<__VA_ARGS__, false>), fg, dim3(NT), 0, st, p, grid); }
         if (tall) {
-            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
-            else if (p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
-            else hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4, 1>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
+            if (kind == KIND_F) PG_FIXUP(0, 2, 4, 1)
+            else if (p.s == 2) PG_FIXUP(3, 2, 4, 1)
+            else PG_FIXUP(1, 2, 4, 1)
         } else if (raw) {
-            if (kind == KIND_F) hipLaunchKernelGGL((conv_fixup_kernel<0, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
-            else if (kind == KIND_T && p.s == 2) hipLaunchKernelGGL((conv_fixup_kernel<3, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
-            else if (kind == KIND_T) hipLaunchKernelGGL((conv_fixup_kernel<1, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
-            else hipLaunchKernelGGL((conv_fixup_kernel<2, 2, 4>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid);
+            if (kind == KIND_F) PG_FIXUP(0, 2, 4, 2)
+            else if (kind == KIND_T && p.s == 2) PG_FIXUP(3, 2, 4, 2)
+            else if (kind == KIND_T) PG_FIXUP(1, 2, 4, 2)
+            else PG_FIXUP(2, 2, 4, 2)
         } else switch (kind) {
-            case KIND_F: hipLaunchKernelGGL((conv_fixup_kernel<0, WMB, 2>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid); break;
-            case KIND_T: hipLaunchKernelGGL((conv_fixup_kernel<1, WMB, 2>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid); break;
-            case KIND_G: hipLaunchKernelGGL((conv_fixup_kernel<2, WMB, 2>), dim3((unsigned)((tiles - p.whole) * 8)), dim3(NT), 0, st, p, grid); break;
+            case KIND_F: PG_FIXUP(0, WMB, 2, 2) break;
+            case KIND_T: PG_FIXUP(1, WMB, 2, 2) break;
+            case KIND_G: PG_FIXUP(2, WMB, 2, 2) break;
         }
+#undef PG_FIXUP
         e = hipGetLastError();
     }
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
@@ -506,13 +576,14 @@ static int conv_fwd_h_impl(const pg_convh_args* a, void* stream, bool query, cha
     const int grid = pick_grid(tiles, p.nslab, p, a->workspace_bytes, kn.force_mode, kn.oversub, kn.contended, 1, 2 * WS_PER_WG);
     const bool split = grid != tiles && !(tiles % grid == 0);
     if (desc) {
-        snprintf(desc, (size_t)desc_len, "conv_h3_kernel<%d, %d, %s>|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d",
-                 (tr && p.k == 5) ? 8 : p.k, p.s, tr ? "true" : "false", grid, tiles, p.nslab, (int)split, p.whole);
+        snprintf(desc, (size_t)desc_len, "conv_h3_kernel<%d, %d, %s>|grid=%d|tiles=%ld|slabs=%d|split=%d|whole=%d|fixup=%s",
+                 (tr && p.k == 5) ? 8 : p.k, p.s, tr ? "true" : "false", grid, tiles, p.nslab, (int)split, p.whole,
+                 !split ? "none" : (fixup_wide(grid, tiles - p.whole) ? "wide" : "plain"));
         return PG_OK;
     }
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = pgconv::launch_h3(kind, p, grid, st);
-    if (e == hipSuccess && split) e = pgconv::launch_h3_fixup(kind, p, grid, (unsigned)((tiles - p.whole) * 16), st);
+    if (e == hipSuccess && split) e = pgconv::launch_h3_fixup(kind, p, grid, (unsigned)(tiles - p.whole), fixup_wide(grid, tiles - p.whole), st);
     if (e != hipSuccess) return pg_fail((int)e, hipGetErrorString(e));
     return PG_OK;
 }

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(NT, 2) void conv_raw_kernel(const IgemmParams p) {
     while (pos < pos_end) {
         const int tile = pos / p.nslab, sb = pos - tile * p.nslab;
         const int se = min(p.nslab, sb + (pos_end - pos));
-        const int m0 = (tile / p.tilesN) * TM, n0 = (tile % p.tilesN) * TN;
+        const int m0 = (tile / p.tilesN) * TM, n0 = p.n_lo + (tile % p.tilesN) * TN;
         const int b0 = n0 / Lcol, t0 = n0 - b0 * Lcol;            // sample / position of the tile's first column
         const int nseg = (t0 + TN - 1) / Lcol + 1;
         const int rlen = SC * (TN - 1) + TJ + RG * (nseg - 1);   // floats of a channel window that are ever read

@@ -472,9 +472,11 @@ void bn_launch_reg(const pg_bn_args* a, int vec, int upt, hipStream_t st) {
 #define PG_BN_LAUNCH(U, V) { if (BWD) hipLaunchKernelGGL((bn_bwd_reg_kernel<U, V>), dim3(a->C), dim3(256), 0, st, *a); \
                              else hipLaunchKernelGGL((bn_fwd_reg_kernel<U, V>), dim3(a->C), dim3(256), 0, st, *a); }
     // (units-per-thread values are the ones hipcc allocates sanely: <8, 4> and <16, 2> take 180-245 VGPRs and spill)
-    if (vec == 4) { if (upt <= 4) PG_BN_LAUNCH(4, 4) else PG_BN_LAUNCH(16, 4) }
-    else if (vec == 2) { PG_BN_LAUNCH(32, 2) }
-    else { if (upt <= 16) PG_BN_LAUNCH(16, 1) else if (upt <= 33) PG_BN_LAUNCH(33, 1) else PG_BN_LAUNCH(64, 1) }
+    // (the small ones are for single clips -- demo.py's batch of one: 64 values per channel -- where walking 16 or 32 empty units
+    // per thread made a 2048-channel layer take 12-26 us)
+    if (vec == 4) { if (upt <= 1) PG_BN_LAUNCH(1, 4) else if (upt <= 4) PG_BN_LAUNCH(4, 4) else PG_BN_LAUNCH(16, 4) }
+    else if (vec == 2) { if (upt <= 2) PG_BN_LAUNCH(2, 2) else PG_BN_LAUNCH(32, 2) }
+    else { if (upt <= 2) PG_BN_LAUNCH(2, 1) else if (upt <= 16) PG_BN_LAUNCH(16, 1) else if (upt <= 33) PG_BN_LAUNCH(33, 1) else PG_BN_LAUNCH(64, 1) }
 #undef PG_BN_LAUNCH
 }
 

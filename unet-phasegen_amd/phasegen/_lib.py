@@ -19,6 +19,8 @@ SCHED_AUTO, SCHED_TILE_PER_WG, SCHED_FORCE_STREAMK, SCHED_NO_RAW, SCHED_NO_TALL,
 SCHED_NO_PS = 128      # wgrad: keep the flat-K raw kernel (no per-sample slabs)
 SCHED_NO_RAW3 = 0x2000  # fp32 F / T: never the one-wave-per-SIMD kernels (conv_raw3.hip)
 SCHED_ALL_RAW3 = 0x4000  # ... those kernels wherever they cover the problem (also the F form of k = 32, which auto leaves on the older ones)
+SCHED_NO_COLSPLIT = 0x20000  # fp32 F / T on conv_raw3: keep the columns past the last full 256-wide tile in the same launch (no tail launch)
+SCHED_COLSPLIT = 0x40000     # ... or always hand them to the tail launch where the geometry allows (tests; the automatic choice prices the tail)
 # (pg_convh_args.schedule bits 5-6 selected tile families that ABI 0.4 removed; bit 12, the surviving conv_h3 family, is a no-op)
 
 c_float_p = C.c_void_p  # device pointers travel as integers

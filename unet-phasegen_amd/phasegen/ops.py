@@ -51,7 +51,7 @@ def set_timer(t):
 
 
 def conv_describe(a, op):
-    """pg_conv_describe: 'kernel<...>|grid=G|tiles=T|slabs=S|split=0/1' for a filled ConvArgs (nothing is launched)."""
+    """pg_conv_describe: 'kernel<...>|grid=G|tiles=T|slabs=S|split=0/1|whole=W|fixup=none/plain/wide' for a filled ConvArgs (nothing is launched)."""
     buf = C.create_string_buffer(256)
     _lib.check(_lib.load().pg_conv_describe(C.byref(a), op, buf, 256), "conv_describe")
     return buf.value.decode()
@@ -211,8 +211,9 @@ def set_conv_schedule(mode):
     bit 7 (value 128): the wgrad keeps the flat-K raw kernel where it would take the per-sample-slab one; bit 13 (value 0x2000):
     never the one-wave-per-SIMD fp32 kernels (conv_raw3.hip), i.e. the two-waves-per-SIMD raw kernels everywhere; bit 14 (0x4000):
     those kernels wherever they cover the problem, also where the automatic choice keeps the older ones (F form of k = 32); bits 15-16:
-    their tile order (1 << 15: row-major, 2 << 15 / 3 << 15: super-rows of 2 / 4 tile rows)."""
-    if mode < 0 or (mode & ~0x1e0ff) or (mode & 3) == 3 or (mode & 0x70) or (mode & 0x6000) == 0x6000:
+    their tile order (1 << 15: row-major, 2 << 15 / 3 << 15: super-rows of 2 / 4 tile rows); bit 17 (0x20000): never split the columns past the
+    last full 256-wide tile off into a tail launch, bit 18 (0x40000): always, where the geometry allows (the automatic choice prices it)."""
+    if mode < 0 or (mode & ~0x7e0ff) or (mode & 0x60000) == 0x60000 or (mode & 3) == 3 or (mode & 0x70) or (mode & 0x6000) == 0x6000:
         raise ValueError("conv schedule: bad mode")
     _tls.schedule = (_tls.schedule & 0xf00) | mode
 
@@ -460,7 +461,7 @@ def conv_fwd_h(xh, Lin, wh, w_shape, stride, pad, transposed=False, y=None, yh=N
 
 
 def conv_fwd_h_describe(a):
-    """pg_conv_fwd_h_describe: 'conv_h[2]_kernel<...>|grid=G|tiles=T|slabs=S|split=0/1|whole=W' for a filled ConvhArgs."""
+    """pg_conv_fwd_h_describe: 'conv_h3_kernel<...>|grid=G|tiles=T|slabs=S|split=0/1|whole=W|fixup=none/plain/wide' for a filled ConvhArgs."""
     buf = C.create_string_buffer(256)
     _lib.check(_lib.load().pg_conv_fwd_h_describe(C.byref(a), buf, 256), "conv_fwd_h_describe")
     return buf.value.decode()
