@@ -158,7 +158,11 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
         for (int sl = sb; sl < se; ++sl) {
             const int cur = (sl - sb) & 1;
             PG_STAMP(0)
+#if defined(PG_G_ABL) && PG_G_ABL == 1      /* dev ablation (wrong results): no gathers inside the loop */
+            kc_next = 16;
+#else
             GRAW_ISSUE(lds + (cur ^ 1) * C::STG, (sl + 1) * BK)
+#endif
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(1)
             {   // fragments + MFMA for slab sl
@@ -168,16 +172,30 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
                 const float* ap = As + (wm * 64 + r) * BK;
                 f32x4 a[2][2];
                 float b[4][8];
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+                // read order = use order (the MFMAs below run kk-major): with the operands of kk = 0, 1 first the first MFMA waits for
+                // 6 of the 20 fragment reads instead of 17 (hipcc keeps source order; it had sorted them operand by operand).  + 0.4 %
+                // on the k = 32 layers, + 0.8-1.3 % on the k = 8 ones.  (Round 4 also tried, on this kernel: the CU's second workgroup
+                // started ~2000 cycles late, or at a higher wave priority, to break the lockstep of the two; the next slab's gathers
+                // issued one per 8 MFMAs instead of at the slab's start -- all neutral.  What the in-loop gathers cost as a whole:
+                // without them (-DPG_G_ABL=1, wrong results) 94 % of the pipe against 88 %; a sample end inside a slab, 1 slab in 8
+                // at 129 frames, costs 4 of those points: 128 frames 88.3 %, 129 frames 84.4 %, tools/dbg/wgrad_frames.py.)
                 if (kc_cur >= 16) {
 #pragma unroll
-                    for (int jb = 0; jb < 4; ++jb)
+                    for (int i = 0; i < 2; ++i) a[i][0] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h) ^ sw) << 2));
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) b[jb][i] = Bw[bbase[jb] + S * i];
-                } else {        // elements kl >= kc_cur live in the second sub-window, which starts at frame 0 of the next sample
+                    for (int ip = 0; ip < 4; ++ip) {
+                        if (ip == 2) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) a[i][1] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + 1) ^ sw) << 2));
+                        }
+#pragma unroll
+                        for (int jb = 0; jb < 4; ++jb) { b[jb][2 * ip] = Bw[bbase[jb] + S * 2 * ip]; b[jb][2 * ip + 1] = Bw[bbase[jb] + S * (2 * ip + 1)]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));        // elements kl >= kc_cur live in the second sub-window, which starts at frame 0 of the next sample
                     // (volatile reads: otherwise hipcc sinks the loads of both paths into one tail with per-element selected
                     // addresses, which cost the common path 60 VALU and left its 32 reads unpaired)
                     typedef const volatile __attribute__((address_space(3))) float* lds_vptr;
@@ -207,12 +225,13 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
                 if (BF) mfma_low_2x4<BF>(a, b, acc);
                 else {
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk)
+                    for (int kk = 0; kk < 8; ++kk) {
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk >> 2][kk & 3], b[j][kk], acc.c[i][j], 0, 0, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -336,14 +355,18 @@ __global__ __launch_bounds__(NT, 2) void conv_g_ps_kernel(const IgemmParams p) {
                 const int w0 = S * gi;                               // window element v sits at row position w0 + v - p
                 f32x4 a[2][2];
                 float b[4][8];
+                // read order = use order (kk-major; see conv_g_raw_kernel)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int i = 0; i < 2; ++i) a[i][0] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h) ^ sw) << 2));
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) a[i][c] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + c) ^ sw) << 2));
+                for (int ip = 0; ip < 4; ++ip) {
+                    if (ip == 2) {
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb)
+                        for (int i = 0; i < 2; ++i) a[i][1] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h + 1) ^ sw) << 2));
+                    }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) b[jb][i] = Bw[bbase[jb] + S * i];
+                    for (int jb = 0; jb < 4; ++jb) { b[jb][2 * ip] = Bw[bbase[jb] + S * 2 * ip]; b[jb][2 * ip + 1] = Bw[bbase[jb] + S * (2 * ip + 1)]; }
+                }
                 if (kc < 16) {                          // the sample's last, padded slab: frames past LP are not this row's
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
