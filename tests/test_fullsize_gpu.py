@@ -59,7 +59,24 @@ def test_conv_layer_at_full_size_bf16x3_split(layer):
         ops.set_conv_precision("fp32")
 
 
-def check_layer(layer, bf16):
+# the reference's own batch (train.py:14-15: 16 x 128 frames): 16 x 65 = 1040 columns = 4 full 256-wide tiles + a 16-column tail launch
+LAYERS_REF_DEFAULT = [("D0", False, C, 2 * C, 32, 2, 16, 128, 0), ("D1", False, 2 * C, 2 * C, 8, 1, 2, 65, 1),
+                      ("U1", True, 4 * C, 2 * C, 8, 1, 2, 62, 2), ("U0", True, 4 * C, 2 * C, 32, 2, 16, 65, 2)]
+
+
+@pytest.mark.parametrize("layer", LAYERS_REF_DEFAULT, ids=[l[0] for l in LAYERS_REF_DEFAULT])
+@pytest.mark.parametrize("sched", [0, 0x20000], ids=["auto(column tail launch)", "no-column-split"])
+def test_conv_layer_at_the_reference_default_batch(layer, sched):
+    """The four layers whose forward or dgrad has 1040 columns at batch 16 x 128 frames, with the tail launch (automatic) and without."""
+    from phasegen import ops
+    ops.set_conv_schedule(sched)
+    try:
+        check_layer(layer, bf16=False, B=16)
+    finally:
+        ops.set_conv_schedule(0)
+
+
+def check_layer(layer, bf16, B=B):
     from phasegen import ops
     name, tr, Cin, Cout, k, s, p, Lin, act = layer
     Lout = ops.convt_out_len(Lin, k, s, p) if tr else ops.conv_out_len(Lin, k, s, p)
@@ -88,6 +105,8 @@ def check_layer(layer, bf16):
     for n in range(48):                                         # y[b,o,t]
         b, o = int(rng.integers(B)), int(rng.integers(Cout))
         t = edge_t[n % 4] if n < 16 else int(rng.integers(Lout))
+        if n % 6 == 5:                                          # the last columns of the flattened (sample, frame) axis: the column tail launch
+            b, t = B - 1, Lout - 1 - int(rng.integers(min(Lout, 64)))
         acc = 0.0
         for j in range(k):
             if tr:
@@ -104,6 +123,8 @@ def check_layer(layer, bf16):
     for n in range(32):                                         # dx[b,c,i] (grad wrt the activated operand)
         b, c = int(rng.integers(B)), int(rng.integers(Cin))
         i = [0, Lin - 1][n % 2] if n < 8 else int(rng.integers(Lin))
+        if n % 6 == 5:
+            b, i = B - 1, Lin - 1 - int(rng.integers(min(Lin, 64)))
         acc = 0.0
         for j in range(k):
             if tr:
