@@ -237,7 +237,11 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
             __builtin_amdgcn_sched_barrier(0);
             PG_STAMP(2)
             kc_cur = kc_next;
+#if defined(PG_G_ABL) && PG_G_ABL == 2      /* dev ablation (wrong results): the barrier does not wait for the gathers */
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
             __syncthreads();
+#endif
             PG_STAMP(3)
         }
         PG_STAMP_FLUSH
