@@ -178,7 +178,8 @@ __global__ __launch_bounds__(NT, 2) void conv_g_raw_kernel(const IgemmParams p) 
                 // started ~2000 cycles late, or at a higher wave priority, to break the lockstep of the two; the next slab's gathers
                 // issued one per 8 MFMAs instead of at the slab's start -- all neutral.  What the in-loop gathers cost as a whole:
                 // without them (-DPG_G_ABL=1, wrong results) 94 % of the pipe against 88 %; a sample end inside a slab, 1 slab in 8
-                // at 129 frames, costs 4 of those points: 128 frames 88.3 %, 129 frames 84.4 %, tools/dbg/wgrad_frames.py.)
+                // at 129 frames, costs under 2 of those points (warm: 128 frames 88.2 %, 129 frames 86.5 %), and a K order without such
+                // slabs -- whole slabs per sample, then "leftover" slabs of one frame of 16 samples -- measured equal: tools/dbg/wgrad_frames.py.)
                 if (kc_cur >= 16) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) a[i][0] = *reinterpret_cast<const f32x4*>(ap + i * 32 * BK + (((2 * h) ^ sw) << 2));
