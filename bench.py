@@ -184,6 +184,28 @@ def synthetic_batch(torch, B, C, L, seed):
                         (torch.rand(B, C, L, device="cuda", generator=gen) * 2 - 1) * torch.pi], dim=1).contiguous()
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when a communicator is created and gloo its
+    rank chatter: route file descriptor 1 to stderr for the whole run and hand the line to the saved descriptor (emit)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(out):
+    line = (json.dumps(out) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, line)
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def kernel_pass(torch, ops, step_fn, steps, fl, peak, step_ms):
     """Second pass: per-launch HIP events, grouped by the kernel symbol each label launches."""
     timer = ops.KernelTimer()
@@ -447,7 +469,7 @@ def run_train(a, torch, dist, world, rank, local):
             out["cpu_baseline"] = cpu_baseline(C, L, a.cpu_threads)
         except Exception as e:          # noqa: BLE001
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-    print(json.dumps(out), flush=True)
+    emit(out)
     if "invalid" in out:
         sys.stdout.flush()
         raise SystemExit(3)
@@ -739,7 +761,7 @@ def run_fwd(a, torch, dist, world, rank, local):
     model = UNetModel(C, 2 * C, gpu_ids=[local], precision=a.precision)
     out = measure_fwd(torch, dist, world, rank, model, C, L, B, a.warmup, a.steps, a.precision)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 def run_e2e(a, torch, dist, world, rank, local):
@@ -749,7 +771,7 @@ def run_e2e(a, torch, dist, world, rank, local):
     model = UNetModel(1024, 2048, gpu_ids=[local], precision=prec)
     out = measure_e2e(torch, dist, world, rank, model, (a.batch if a.batch != 64 else 32), a.warmup, a.steps, prec)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 def main():
@@ -790,6 +812,8 @@ def main():
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or a.dp_selftest:
+        quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world == 1:
