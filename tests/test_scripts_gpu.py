@@ -76,7 +76,7 @@ def test_bench_contract_line_and_dp_selftest(tmp_path):
     out = run([os.path.join(ROOT, "bench.py"), "--channels", "32", "--frames", "64", "--batch", "4", "--steps", "2", "--warmup", "1",
                "--no-cpu-baseline", "--no-other-precisions", "--dp-selftest"], cwd=str(tmp_path))
     lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and out.strip() == lines[0], out[:400]     # stdout holds the line and nothing else (RCCL's banner goes to stderr)
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "kernels"):
@@ -104,7 +104,7 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(tmp_path):
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--channels", "32", "--frames", "64",
                "--batch", "4", "--steps", "2", "--warmup", "1", "--rehearse-on-one-gpu"], cwd=str(tmp_path))
     lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and out.strip() == lines[0], out[:400]     # ... also with two ranks (gloo's rank chatter, the other rank's prints)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2 * 4 * 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]        # whole-job frames / max-over-ranks time
