@@ -31,7 +31,7 @@ def shard_grads(rank):
     return {k: p[k].grad.detach().clone() for k in detgen.param_order()}
 
 
-def worker(rank, port, q, compress=None):
+def worker(rank, port, q, compress=None, WORLD=WORLD):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
@@ -63,12 +63,12 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("compress", [None, "bf16"])
-def test_bucketed_allreduce_equals_mean_of_replica_grads(compress):
+@pytest.mark.parametrize("compress,WORLD", [(None, 2), ("bf16", 2), (None, 4)], ids=["fp32-2-ranks", "bf16-2-ranks", "fp32-4-ranks"])
+def test_bucketed_allreduce_equals_mean_of_replica_grads(compress, WORLD):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, port, q, compress)) for r in range(WORLD)]
+    procs = [ctx.Process(target=worker, args=(r, port, q, compress, WORLD)) for r in range(WORLD)]
     for p in procs:
         p.start()
     avg = q.get(timeout=240)
@@ -77,7 +77,7 @@ def test_bucketed_allreduce_equals_mean_of_replica_grads(compress):
         assert p.exitcode == 0
     want = [shard_grads(r) for r in range(WORLD)]
     for k in detgen.param_order():
-        w = (want[0][k] + want[1][k]).numpy() / WORLD
+        w = sum(wr[k] for wr in want).numpy() / WORLD
         # fp32 payload: exact to rounding; bf16 payload: each rank's gradient and the sum are rounded to bf16
         tol = 1e-6 if compress is None else 1.2e-2
         assert np.max(np.abs(avg[k] - w)) <= tol * max(np.max(np.abs(w)), 1e-12), k
